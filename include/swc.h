@@ -1,0 +1,185 @@
+/*
+ * swc.h — C-ABI of libswc_hip.so: the MI355X (gfx950) kernels behind the
+ * SimWhisper-Codec encode -> quantize -> vocode hot path.
+ *
+ * The reference has no native layer: every entry point below replaces a run of
+ * stock ATen calls inside one reference function (cited per entry, paths
+ * relative to the reference repo).  The Python host (simwhisper_codec_amd/codec.py)
+ * binds these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types.  All pointers are DEVICE pointers
+ *    unless a parameter is documented as host.
+ *  - activations are "frame-major": a (B, C, T) reference tensor is stored as
+ *    [B][T][C] (channels contiguous), so a row is one frame/token.
+ *  - every function only ENQUEUES work on `stream` and returns: 0 on success,
+ *    a negative SWC_E_* code otherwise (swc_last_error() gives the text).
+ *    Nothing allocates, synchronises or throws; the caller owns all memory.
+ *  - `stream` is a hipStream_t passed as void*.
+ *  - dtype codes: SWC_F32 = 0, SWC_BF16 = 1.
+ */
+#ifndef SWC_H_
+#define SWC_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWC_OK 0
+#define SWC_E_ARG (-1)     /* bad shape / alignment / null pointer */
+#define SWC_E_LAUNCH (-2)  /* hipLaunch error */
+#define SWC_E_NODEV (-3)   /* no HIP device */
+
+#define SWC_F32 0
+#define SWC_BF16 1
+
+#define SWC_ACT_NONE 0
+#define SWC_ACT_GELU 1 /* exact erf GELU == nn.GELU() / ACT2FN["gelu"] */
+
+int swc_version(void);
+const char* swc_last_error(void);
+/* number of visible HIP devices, or SWC_E_NODEV */
+int swc_device_count(void);
+
+/*
+ * GEMM / implicit-GEMM Conv1d on MFMA:  C = epi(A (*) W^T)
+ *
+ * Replaces nn.Linear / nn.Conv1d calls: audiocodec/nn/modules.py:159-161,185
+ * (q/k/v/out proj), :225-226 (fc1+GELU, fc2), :316-319 (conv1, conv2),
+ * :544,548 (in_proj,to_latent), :43,45 (ResidualUnit convs), :615,621,
+ * :464-465 (deconv as GEMM, see swc_deconv_col2im), :1494 (embed),
+ * :1240-1244 (pwconv1+GELU, pwconv2*gamma+res), :1064 (head.out), and the
+ * DFT / mel / inverse-DFT contractions of feature_extractor.py:99-103 and
+ * modules.py:861.
+ *
+ * A: [rows_in][lda]  element type a_dtype.  W: [N][ldw] (taps*K columns, tap-major),
+ * same element type as A.  C: [M][ldc] of c_dtype.
+ * Output row r = b*t_out + t reads, for tap j, input row
+ *   b*t_in + t*stride + j*dil - pad   (zero if outside [0, t_in)).
+ * A plain GEMM is taps=1, stride=1, dil=1, pad=0, t_in=t_out=M.
+ * epilogue: v = acc + bias[n]; v = act(v); v *= gamma[n]; v += residual[r][n].
+ * K must be a multiple of 4 (f32) / 8 (bf16); lda, ldw keep rows 16-byte aligned.
+ */
+typedef struct swc_gemm_args {
+    const void* A;
+    const void* W;
+    void* C;
+    const float* bias;     /* [N] or NULL */
+    const float* gamma;    /* [N] or NULL */
+    const float* residual; /* [M][ldr] f32 or NULL (may alias C when c_dtype == F32) */
+    int64_t lda, ldw, ldc, ldr;
+    int32_t M, N, K;
+    int32_t taps, dil, stride, pad, t_in, t_out;
+    int32_t a_dtype, c_dtype, act;
+} swc_gemm_args;
+int swc_gemm(const swc_gemm_args* args, void* stream);
+
+/*
+ * Varlen multi-head self-attention, head_dim 64, non-causal, keys >= len masked.
+ * Replaces VarLenAttention score/softmax/PV (modules.py:164-182) incl. the
+ * additive mask of :111-143.  qkv: [B][T][3*H*64] (q | k | v, q pre-scaled by
+ * 64^-0.5 through the packed weights), out: [B][T][H*64].  Rows t >= lens[b]
+ * produce finite don't-care values (the caller masks them, modules.py:358,460).
+ * dtype is the element type of qkv and out.
+ */
+int swc_attention(const void* qkv, void* out, const int32_t* lens, int32_t B, int32_t T,
+                  int32_t H, int32_t dtype, void* stream);
+
+/*
+ * LayerNorm over the last dim.  Replaces nn.LayerNorm calls modules.py:216,224,
+ * 353,457 (eps 1e-5) and :1239,1499,1503 (eps 1e-6).  x: [B][t_in][C] f32;
+ * y: [B][t_out][C] (y_dtype).  Only rows t < min(t_in, t_out) are written; when lens != NULL
+ * rows t >= lens[b] are written as zeros (torch.where(mask, h, 0), modules.py:358,460).
+ */
+int swc_layernorm(const float* x, void* y, const float* w, const float* b, const int32_t* lens,
+                  int32_t B, int32_t t_in, int32_t t_out, int32_t C, float eps, int32_t y_dtype,
+                  void* stream);
+
+/*
+ * ConvNeXt front half: depthwise Conv1d(k=7, pad=3, groups=C) + LayerNorm(eps)
+ * (modules.py:1233-1239).  x: [B][T][C] f32, w: [7][C], y: [B][T][C] (y_dtype).
+ */
+int swc_dwconv7_ln(const float* x, void* y, const float* w, const float* bias, const float* ln_w,
+                   const float* ln_b, int32_t B, int32_t T, int32_t C, float eps, int32_t y_dtype,
+                   void* stream);
+
+/*
+ * Anti-aliased SnakeBeta (Activation1d): replicate-pad, 2x kaiser-sinc upsample,
+ * x + sin^2(x*a)/(b+1e-9), 2x low-pass downsample.  Replaces
+ * alias_free_torch/act.py:23-28 + resample.py:25-33,46-49 + filter.py:83-92 +
+ * activations.py:107-120.  x: [B][T][C] f32; alpha/beta: [C] already exp()'d
+ * (alpha_logscale); filt: host pointer to the 12 taps; y: [B][T][C] (y_dtype).
+ */
+int swc_snake_aa(const float* x, void* y, const float* alpha, const float* beta,
+                 const float* filt_host12, int32_t B, int32_t T, int32_t C, int32_t y_dtype,
+                 void* stream);
+
+/*
+ * Grouped finite scalar quantiser, levels [8,7,6,6] per group of 4 channels.
+ * Replaces GroupFiniteScalarQuantizer.forward / .decode (quantizer.py:273-318,
+ * 129-157,169-200,207-224).
+ * encode: z [B][T][ldz>=4G] f32 -> zq [B][t_pad][4G] f32 (zeros for t >= lens[b] and t >= T),
+ *         codes [G][B][t_pad] int32 (same masking).
+ * decode: codes [G][B][T] int64 -> zq [B][T][ldq] f32, cols >= 4G zero, masked by lens.
+ * consts_host12 (HOST pointer): scale[4] | offset[4] | shift[4] as f32, computed by the
+ * caller with the reference's own formula (quantizer.py:131-137) so that the constants
+ * are bit-identical to the ones the reference derives at run time.
+ */
+int swc_fsq_encode(const float* z, int64_t ldz, float* zq, int32_t* codes, const int32_t* lens,
+                   const float* consts_host12, int32_t B, int32_t T, int32_t t_pad, int32_t G,
+                   void* stream);
+int swc_fsq_decode(const int64_t* codes, float* zq, int64_t ldq, const int32_t* lens, int32_t B,
+                   int32_t T, int32_t G, void* stream);
+
+/*
+ * Whisper log-mel front end (feature_extractor.py:86-112,207-214), three steps
+ * around two swc_gemm calls (windowed DFT, mel filter bank):
+ *  frames: wav [B][ld_wav] f32 with n[b] valid samples, virtually zero-padded to
+ *          n_pad (480000) then reflect-padded by 200 -> frames [B][T][400]
+ *          (frame t = padded samples t*160-200 .. +399).
+ *  power : dft [rows][ld] (re 0..200 | im 201..401) -> pw [rows][ldp] (|X|^2, cols >= 201 zero)
+ *  logmax: mel [B][T][ld] (first n_mel cols valid) -> in-place log10(max(x,1e-10)),
+ *          per-utterance max into umax[b] (caller presets umax to -10 when padding
+ *          frames beyond T exist, else -inf)
+ *  final : y = (max(x, umax[b]-8)+4)/4 written to out [B][T][ldo] (out dtype),
+ *          cols n_mel..ldo zeroed.
+ */
+int swc_mel_frames(const float* wav, int64_t ld_wav, const int32_t* n, int32_t n_pad,
+                   float* frames, int32_t B, int32_t T, void* stream);
+int swc_mel_power(const float* dft, int64_t ld, float* pw, int64_t ldp, int64_t rows,
+                  void* stream);
+int swc_mel_logmax(float* mel, int64_t ld, float* umax, int32_t B, int32_t T, int32_t n_mel,
+                   void* stream);
+int swc_mel_final(const float* mel, int64_t ld, const float* umax, void* out, int64_t ldo,
+                  int32_t B, int32_t T, int32_t n_mel, int32_t out_dtype, void* stream);
+
+/*
+ * ConvTranspose1d(k=3, stride s, pad 0) tail: y3 [B][T][3][C] (the GEMM of the
+ * input against the three taps) -> out [B][t_out][ldo] = bias + sum_j y3[t][j] at
+ * position s*t + j (modules.py:464-465).  t_out <= (T-1)*s + 3; cols >= C zeroed.
+ */
+int swc_deconv_col2im(const float* y3, const float* bias, void* out, int64_t ldo, int32_t B,
+                      int32_t T, int32_t C, int32_t s, int32_t t_out, int32_t out_dtype,
+                      void* stream);
+
+/*
+ * ISTFT head (modules.py:1065-1081, 861-884):
+ *  spec: h [rows][ldh] (mag 0..320 | phase 321..641) -> s [rows][lds]:
+ *        re = min(exp(mag),100)*cos(p) at col k, im at col 321+k, pad zero.
+ *  ola : frames [B][T][640] (windowed inverse DFT, a swc_gemm) -> wav [B][T*160]:
+ *        overlap-add hop 160, crop 240, divide by the hann^2 envelope.
+ */
+int swc_istft_spec(const float* h, int64_t ldh, void* s, int64_t lds, int64_t rows,
+                   int32_t s_dtype, void* stream);
+int swc_istft_ola(const float* frames, const float* window_sq, float* wav, int32_t B, int32_t T,
+                  void* stream);
+
+/* f32 -> bf16 cast (weight packing / mode switches) */
+int swc_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWC_H_ */

@@ -1,0 +1,183 @@
+"""Torch-tensor front ends of the C-ABI kernels.  PyTorch is plumbing here: it owns
+device memory and the stream; every computation is a libswc_hip.so call.
+
+All activations are frame-major: a reference (B, C, T) tensor lives as [B, T, C].
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, BF16, F32  # noqa: F401
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _chk(t, name, dtype=None):
+    if not t.is_cuda:
+        raise _lib.SwcError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.SwcError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def gemm(A, W, M, N, K, *, out=None, out_dtype=None, lda=None, ldw=None, ldc=None, bias=None, gamma=None,
+         residual=None, ldr=None, act=ACT_NONE, taps=1, dil=1, stride=1, pad=0, t_in=None, t_out=None):
+    """C[M, N] = epi(A (*) W^T); see include/swc.h swc_gemm.  A: [.., lda], W: [N, ldw]."""
+    lib = _lib.load()
+    _chk(A, "gemm A"); _chk(W, "gemm W")
+    if A.dtype != W.dtype:
+        raise _lib.SwcError(f"gemm: A is {A.dtype} but W is {W.dtype}")
+    lda = A.stride(-2) if lda is None else lda
+    ldw = W.stride(-2) if ldw is None else ldw
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=out_dtype or torch.float32)
+    ldc = out.stride(-2) if ldc is None else ldc
+    a = _lib.GemmArgs()
+    a.A, a.W, a.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.gamma = gamma.data_ptr() if gamma is not None else None
+    a.residual = residual.data_ptr() if residual is not None else None
+    a.lda, a.ldw, a.ldc = lda, ldw, ldc
+    a.ldr = (residual.stride(-2) if ldr is None else ldr) if residual is not None else 0
+    a.M, a.N, a.K = M, N, K
+    a.taps, a.dil, a.stride, a.pad = taps, dil, stride, pad
+    a.t_in = M if t_in is None else t_in
+    a.t_out = M if t_out is None else t_out
+    if M == 0:
+        return out
+    a.a_dtype, a.c_dtype, a.act = _DT[A.dtype], _DT[out.dtype], act
+    _lib.check(lib.swc_gemm(C.byref(a), _stream()), "swc_gemm")
+    return out
+
+
+def attention(qkv, lens, B, T, H, out=None):
+    lib = _lib.load()
+    _chk(qkv, "attention qkv"); _chk(lens, "attention lens", torch.int32)
+    if out is None:
+        out = torch.empty((B, T, H * 64), device=qkv.device, dtype=qkv.dtype)
+    _lib.check(lib.swc_attention(_ptr(qkv), _ptr(out), _ptr(lens), B, T, H, _DT[qkv.dtype], _stream()),
+               "swc_attention")
+    return out
+
+
+def layernorm(x, w, b, eps, *, B, t_in, C_, t_out=None, lens=None, out=None, out_dtype=torch.float32):
+    lib = _lib.load()
+    _chk(x, "layernorm x", torch.float32)
+    t_out = t_in if t_out is None else t_out
+    if out is None:
+        out = torch.empty((B, t_out, C_), device=x.device, dtype=out_dtype)
+    _lib.check(lib.swc_layernorm(_ptr(x), _ptr(out), _ptr(w), _ptr(b), _ptr(lens), B, t_in, t_out, C_, eps,
+                                 _DT[out.dtype], _stream()), "swc_layernorm")
+    return out
+
+
+def dwconv7_ln(x, w7, bias, ln_w, ln_b, eps, *, B, T, C_, out=None, out_dtype=torch.float32):
+    lib = _lib.load()
+    _chk(x, "dwconv7_ln x", torch.float32)
+    if out is None:
+        out = torch.empty((B, T, C_), device=x.device, dtype=out_dtype)
+    _lib.check(lib.swc_dwconv7_ln(_ptr(x), _ptr(out), _ptr(w7), _ptr(bias), _ptr(ln_w), _ptr(ln_b), B, T, C_, eps,
+                                  _DT[out.dtype], _stream()), "swc_dwconv7_ln")
+    return out
+
+
+def snake_aa(x, alpha, beta, filt12, *, B, T, C_, out=None, out_dtype=torch.float32):
+    """filt12: python sequence of the 12 kaiser-sinc taps (host)."""
+    lib = _lib.load()
+    _chk(x, "snake_aa x", torch.float32)
+    if out is None:
+        out = torch.empty((B, T, C_), device=x.device, dtype=out_dtype)
+    f = (C.c_float * 12)(*[float(v) for v in filt12])
+    _lib.check(lib.swc_snake_aa(_ptr(x), _ptr(out), _ptr(alpha), _ptr(beta), f, B, T, C_, _DT[out.dtype],
+                                _stream()), "swc_snake_aa")
+    return out
+
+
+def fsq_encode(z, ldz, lens, consts12, *, B, T, t_pad, G):
+    lib = _lib.load()
+    _chk(z, "fsq_encode z", torch.float32); _chk(lens, "fsq_encode lens", torch.int32)
+    zq = torch.empty((B, t_pad, 4 * G), device=z.device, dtype=torch.float32)
+    codes = torch.empty((G, B, t_pad), device=z.device, dtype=torch.int32)
+    k = (C.c_float * 12)(*[float(v) for v in consts12])
+    _lib.check(lib.swc_fsq_encode(_ptr(z), ldz, _ptr(zq), _ptr(codes), _ptr(lens), k, B, T, t_pad, G, _stream()),
+               "swc_fsq_encode")
+    return zq, codes
+
+
+def fsq_decode(codes, lens, *, B, T, G, ldq=None):
+    lib = _lib.load()
+    _chk(codes, "fsq_decode codes", torch.int64); _chk(lens, "fsq_decode lens", torch.int32)
+    ldq = 4 * G if ldq is None else ldq
+    zq = torch.empty((B, T, ldq), device=codes.device, dtype=torch.float32)
+    _lib.check(lib.swc_fsq_decode(_ptr(codes), _ptr(zq), ldq, _ptr(lens), B, T, G, _stream()), "swc_fsq_decode")
+    return zq
+
+
+def mel_frames(wav, n, n_pad, *, B, T):
+    lib = _lib.load()
+    _chk(wav, "mel_frames wav", torch.float32); _chk(n, "mel_frames n", torch.int32)
+    frames = torch.empty((B, T, 400), device=wav.device, dtype=torch.float32)
+    _lib.check(lib.swc_mel_frames(_ptr(wav), wav.stride(0), _ptr(n), n_pad, _ptr(frames), B, T, _stream()),
+               "swc_mel_frames")
+    return frames
+
+
+def mel_power(dft, ld, rows, ldp):
+    lib = _lib.load()
+    pw = torch.empty((rows, ldp), device=dft.device, dtype=torch.float32)
+    _lib.check(lib.swc_mel_power(_ptr(dft), ld, _ptr(pw), ldp, rows, _stream()), "swc_mel_power")
+    return pw
+
+
+def mel_logmax(mel, ld, umax, *, B, T, n_mel):
+    lib = _lib.load()
+    _lib.check(lib.swc_mel_logmax(_ptr(mel), ld, _ptr(umax), B, T, n_mel, _stream()), "swc_mel_logmax")
+
+
+def mel_final(mel, ld, umax, *, B, T, n_mel, ldo, out_dtype=torch.float32):
+    lib = _lib.load()
+    out = torch.empty((B, T, ldo), device=mel.device, dtype=out_dtype)
+    _lib.check(lib.swc_mel_final(_ptr(mel), ld, _ptr(umax), _ptr(out), ldo, B, T, n_mel, _DT[out_dtype], _stream()),
+               "swc_mel_final")
+    return out
+
+
+def deconv_col2im(y3, bias, *, B, T, C_, s, t_out, ldo=None, out_dtype=torch.float32):
+    lib = _lib.load()
+    ldo = C_ if ldo is None else ldo
+    out = torch.empty((B, t_out, ldo), device=y3.device, dtype=out_dtype)
+    _lib.check(lib.swc_deconv_col2im(_ptr(y3), _ptr(bias), _ptr(out), ldo, B, T, C_, s, t_out, _DT[out_dtype],
+                                     _stream()), "swc_deconv_col2im")
+    return out
+
+
+def istft_spec(h, ldh, rows, lds, out_dtype=torch.float32):
+    lib = _lib.load()
+    s = torch.empty((rows, lds), device=h.device, dtype=out_dtype)
+    _lib.check(lib.swc_istft_spec(_ptr(h), ldh, _ptr(s), lds, rows, _DT[out_dtype], _stream()), "swc_istft_spec")
+    return s
+
+
+def istft_ola(frames, window_sq, *, B, T):
+    lib = _lib.load()
+    wav = torch.empty((B, T * 160), device=frames.device, dtype=torch.float32)
+    _lib.check(lib.swc_istft_ola(_ptr(frames), _ptr(window_sq), _ptr(wav), B, T, _stream()), "swc_istft_ola")
+    return wav
+
+
+def cast_bf16(x):
+    lib = _lib.load()
+    _chk(x, "cast_bf16 x", torch.float32)
+    x = x.contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    _lib.check(lib.swc_cast_f32_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "swc_cast_f32_bf16")
+    return y
