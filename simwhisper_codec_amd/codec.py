@@ -1,0 +1,486 @@
+"""AudioCodec — the reference's model surface (audiocodec/model.py:15-396) on MI355X.
+
+Same constructor argument (`generator_params` of the YAML), same checkpoint layout
+(`state_dict()` keys and shapes, strict load), same methods and return dicts:
+`load_from_checkpoint`, `encode`, `decode`, `inference_tokenize`,
+`inference_detokenize`, `forward`, `remove_weight_norm`.  The computation is a sequence
+of libswc_hip.so calls (include/swc.h) on frame-major [B, T, C] buffers; PyTorch only
+owns the memory and the stream.  There is no CPU path: using the model on a non-HIP
+device raises SwcError.
+
+Work the reference does and this path provably does not need:
+  * the 30 s padding of every tokenize call (feature_extractor.py:207-214): rows beyond an
+    utterance's length never reach valid rows, so mel / encoder run on the valid frames
+    (+2 halo frames for the conv stem) — reference measured identical codes, |diff| 3e-6;
+  * the down-sampler over 375 frames: it runs on ceil(len/4)+64 frames (its receptive
+    field is +-59 frames) of the zero-extended encoder output;
+  * masks, permutes and per-utterance Python copy loops (model.py:293-295,358-360).
+Ragged `decode` batches are padded to the batch maximum exactly like the reference,
+because its un-masked up-sampler / Vocos make short utterances depend on that maximum.
+"""
+import logging
+import os
+
+import torch
+import torch.nn as nn
+import yaml
+
+from . import ops, spec
+from ._lib import SwcError
+
+PRECISIONS = ("fp32", "mixed", "bf16")
+
+
+class _Node(nn.Module):
+    """Bare container so that buffers can sit at the reference's dotted paths."""
+
+
+def _register(root, name, tensor):
+    parts = name.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, _Node())
+        mod = mod._modules[p]
+    mod.register_buffer(parts[-1], tensor)
+
+
+class _Layer:
+    __slots__ = ("ln1", "wqkv", "bqkv", "wo", "bo", "ln2", "w1", "b1", "w2", "b2")
+
+
+class _Packed:
+    """Device-resident, GEMM-ready weights for one compute dtype per stage."""
+
+
+def _fold_wn(sd, p):
+    g, v = sd[p + ".weight_g"], sd[p + ".weight_v"]
+    nrm = v.reshape(v.shape[0], -1).norm(dim=1).view(-1, 1, 1)
+    return g * v / nrm
+
+
+class AudioCodec(nn.Module):
+    def __init__(self, generator_params, precision="mixed"):
+        super().__init__()
+        gp = generator_params
+        self.generator_params = gp
+        self.input_sample_rate = gp["input_sample_rate"]
+        self.output_sample_rate = gp["output_sample_rate"]
+        self.max_audio_seconds = 30
+        self.encoder_downsample_rate = gp["encoder_downsample_rate"]
+        self.decoder_upsample_rate = gp["decoder_upsample_rate"]
+        q = gp["quantizer"]
+        self.num_groups = q["num_groups"]
+        self.codebook_dim_per_group = len(q["num_levels_per_group"])
+        if list(q["num_levels_per_group"]) != [8, 7, 6, 6]:
+            raise SwcError("the FSQ kernels are built for num_levels_per_group = [8, 7, 6, 6]")
+        enc = dict(gp["acoustic_encoder"])
+        # keys the reference pops before building the encoder (model.py:35-39)
+        self.freeze_acoustic_encoder_flag = enc.pop("freeze", False)
+        self.whisper_model_path = enc.pop("whisper_model_path", None)
+        self.init_from_whisper = enc.pop("init_from_whisper", False)
+        if not enc.get("is_acoustic", False):
+            raise SwcError("only the acoustic (no positional embedding, no GELU stem) encoder is on the hot path")
+        for sect, key in (("acoustic_encoder", "encoder_attention_heads"), ("acoustic_decoder", "decoder_attention_heads")):
+            if gp[sect]["d_model"] // gp[sect][key] != spec.HEAD_DIM:
+                raise SwcError(f"{sect}: head_dim must be {spec.HEAD_DIM}")
+        if gp["vocos"]["n_fft"] != 640 or gp["vocos"]["hop_size"] != 160 or gp["vocos"].get("padding", "same") != "same":
+            raise SwcError("the ISTFT kernels are built for n_fft 640 / hop 160 / 'same' padding")
+        self.precision = precision
+        for name, (shape, dtype) in spec.state_shapes(gp).items():
+            _register(self, name, torch.zeros(shape, dtype=dtype))
+        self._pk = None
+        self._pk_key = None
+
+    # ------------------------------------------------------------ plumbing
+    @property
+    def precision(self):
+        return self._precision
+
+    @precision.setter
+    def precision(self, p):
+        if p not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}")
+        self._precision = p
+        self._pk = None
+
+    def _apply(self, fn, *a, **k):
+        self._pk = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._pk = None
+        return super().load_state_dict(*a, **k)
+
+    def remove_weight_norm(self):
+        """Weight norm is folded once when the weights are packed; kept for API parity (model.py:101-110)."""
+        return self
+
+    @classmethod
+    def load_from_checkpoint(cls, config_path: str, ckpt_path: str):
+        """model.py:375-396: YAML -> model, `.pt` (bare state_dict or {'model': ...}) -> strict load.
+        The file is read with weights_only=True (nothing in it is executed)."""
+        logging.info(f"Loading model from {config_path} and {ckpt_path}")
+        with open(config_path, "r") as f:
+            config = yaml.safe_load(f)
+        model = cls(config["generator_params"])
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+        model.load_state_dict(ckpt["model"] if "model" in ckpt else ckpt, strict=True)
+        return model
+
+    def _device(self):
+        return self._buffers_device()
+
+    def _buffers_device(self):
+        return next(self.buffers()).device
+
+    # ------------------------------------------------------------- packing
+    def _dtypes(self):
+        enc = torch.float32 if self._precision in ("fp32", "mixed") else torch.bfloat16
+        dec = torch.float32 if self._precision == "fp32" else torch.bfloat16
+        return enc, dec
+
+    def _packed(self):
+        dev = self._buffers_device()
+        if dev.type != "cuda":
+            raise SwcError("AudioCodec runs on the HIP device only (call .to('cuda')); there is no CPU fallback")
+        key = (dev, self._precision)
+        if self._pk is not None and self._pk_key == key:
+            return self._pk
+        self._pk = self._pack(dev)
+        self._pk_key = key
+        return self._pk
+
+    @torch.no_grad()
+    def _pack(self, dev):
+        gp = self.generator_params
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        edt, ddt = self._dtypes()
+        P = _Packed()
+        P.edt, P.ddt = edt, ddt
+
+        def W(t, dt):
+            t = t.to(dev, torch.float32).contiguous()
+            return ops.cast_bf16(t) if dt == torch.bfloat16 else t
+
+        def V(t):
+            return t.to(dev, torch.float32).contiguous()
+
+        def conv_w(w):  # (Cout, Cin, k) -> [Cout][k][Cin]
+            return w.permute(0, 2, 1).reshape(w.shape[0], -1)
+
+        def layers(prefix, n, dt):
+            out = []
+            for i in range(n):
+                p = f"{prefix}.layers.{i}."
+                L = _Layer()
+                s = spec.HEAD_DIM ** -0.5  # q = (Wq x + bq) * s (modules.py:159): folded, exact (power of two)
+                wq, wk, wv = sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"]
+                L.wqkv = W(torch.cat([wq * s, wk, wv], 0), dt)
+                L.bqkv = V(torch.cat([sd[p + "self_attn.q_proj.bias"] * s, torch.zeros_like(sd[p + "self_attn.q_proj.bias"]),
+                                      sd[p + "self_attn.v_proj.bias"]]))
+                L.wo, L.bo = W(sd[p + "self_attn.out_proj.weight"], dt), V(sd[p + "self_attn.out_proj.bias"])
+                L.ln1 = (V(sd[p + "self_attn_layer_norm.weight"]), V(sd[p + "self_attn_layer_norm.bias"]))
+                L.ln2 = (V(sd[p + "final_layer_norm.weight"]), V(sd[p + "final_layer_norm.bias"]))
+                L.w1, L.b1 = W(sd[p + "fc1.weight"], dt), V(sd[p + "fc1.bias"])
+                L.w2, L.b2 = W(sd[p + "fc2.weight"], dt), V(sd[p + "fc2.bias"])
+                out.append(L)
+            return out
+
+        def res_units(prefix, dt):
+            units = []
+            for i, d in enumerate((1, 3, 9)):
+                b = f"{prefix}.res_blocks.{i}.block."
+                u = {"dil": d}
+                for a in ("0", "2"):
+                    fu, fd = sd[b + a + ".upsample.filter"].reshape(-1), sd[b + a + ".downsample.lowpass.filter"].reshape(-1)
+                    if not torch.equal(fu.cpu(), fd.cpu()):
+                        raise SwcError("anti-alias up/down filters differ; the fused kernel assumes one 12-tap filter")
+                    u["f" + a] = [float(x) for x in fu.cpu()]
+                    u["a" + a] = V(torch.exp(sd[b + a + ".act.alpha"].cpu().float()))
+                    u["b" + a] = V(torch.exp(sd[b + a + ".act.beta"].cpu().float()))
+                u["w1"], u["c1"] = W(conv_w(_fold_wn(sd, b + "1")), dt), V(sd[b + "1.bias"])
+                u["w3"], u["c3"] = W(conv_w(_fold_wn(sd, b + "3")), dt), V(sd[b + "3.bias"])
+                units.append(u)
+            return units
+
+        # ---- encode side
+        e = gp["acoustic_encoder"]
+        P.D, P.He, P.n_mel = e["d_model"], e["encoder_attention_heads"], e["num_mel_bins"]
+        P.dft = V(spec.dft_basis_400())                                    # [402][400] f32 always
+        fb = torch.from_numpy(spec.slaney_mel_filters(n_mels=P.n_mel)).float().T.contiguous()  # [80][201]
+        P.melw = V(torch.nn.functional.pad(fb, (0, 208 - 201)))           # [80][208]
+        P.c1w, P.c1b = W(conv_w(sd["acoustic_encoder.conv1.weight"]), edt), V(sd["acoustic_encoder.conv1.bias"])
+        P.c2w, P.c2b = W(conv_w(sd["acoustic_encoder.conv2.weight"]), edt), V(sd["acoustic_encoder.conv2.bias"])
+        P.enc_layers = layers("acoustic_encoder", e["encoder_layers"], edt)
+        P.enc_ln = (V(sd["acoustic_encoder.layer_norm.weight"]), V(sd["acoustic_encoder.layer_norm.bias"]))
+        ds = gp["downsample"]
+        P.stack, P.hid, P.lat = ds["stack_factor"], ds["hidden_dim"], ds["latent_dim"]
+        w = _fold_wn(sd, "downsample.in_proj")[:, :, 0]                     # [hid][d*s + s_idx]
+        w = w.view(P.hid, ds["in_dim"], P.stack).permute(0, 2, 1).reshape(P.hid, -1)  # -> [hid][s_idx*D + d]
+        P.inw, P.inb = W(w, edt), V(sd["downsample.in_proj.bias"])
+        P.down_units = res_units("downsample", edt)
+        P.tlw, P.tlb = W(_fold_wn(sd, "downsample.to_latent")[:, :, 0], edt), V(sd["downsample.to_latent.bias"])
+        q = gp["quantizer"]
+        P.fsq = spec.fsq_constants(q["num_levels_per_group"], q.get("eps", 1e-3))
+
+        # ---- decode side
+        us = gp["upsample"]
+        P.uhid = us["hidden_dim"]
+        P.flw, P.flb = W(_fold_wn(sd, "upsample.from_latent")[:, :, 0], ddt), V(sd["upsample.from_latent.bias"])
+        P.up_units = res_units("upsample", ddt)
+        w = _fold_wn(sd, "upsample.to_stacked")[:, :, 0]                    # [(d*s + s_idx)][hid]
+        od = us["out_dim"]
+        w = w.view(od, P.stack, -1).permute(1, 0, 2).reshape(od * P.stack, -1)
+        b = sd["upsample.to_stacked.bias"].view(od, P.stack).T.reshape(-1)
+        P.tsw, P.tsb = W(w, ddt), V(b)
+        dc = gp["acoustic_decoder"]
+        P.Dd, P.Hd = dc["d_model"], dc["decoder_attention_heads"]
+        P.dec_layers = layers("acoustic_decoder", dc["decoder_layers"], ddt)
+        P.dec_ln = (V(sd["acoustic_decoder.layer_norm.weight"]), V(sd["acoustic_decoder.layer_norm.bias"]))
+        w1 = sd["acoustic_decoder.deconv1.weight"]                          # (ci, co, j)
+        P.d1w, P.d1b = W(w1.permute(2, 1, 0).reshape(-1, w1.shape[0]), ddt), V(sd["acoustic_decoder.deconv1.bias"])
+        w2 = sd["acoustic_decoder.deconv2.weight"]                          # (ci, co, j): conv with flipped taps, pad 2
+        P.d2w = W(w2.flip(2).permute(1, 2, 0).reshape(w2.shape[1], -1), ddt)
+        P.d2b = V(sd["acoustic_decoder.deconv2.bias"])
+        v = gp["vocos"]
+        P.vdim, P.vint, P.vin = v["dim"], v["intermediate_dim"], v["input_channels"]
+        p = "vocos.backbone."
+        P.emw, P.emb = W(conv_w(sd[p + "embed.weight"]), ddt), V(sd[p + "embed.bias"])
+        P.vnorm = (V(sd[p + "norm.weight"]), V(sd[p + "norm.bias"]))
+        P.blocks = []
+        for i in range(v["num_layers"]):
+            b_ = f"{p}convnext.{i}."
+            P.blocks.append(dict(
+                dw=V(sd[b_ + "dwconv.weight"][:, 0].T), db=V(sd[b_ + "dwconv.bias"]),
+                ln=(V(sd[b_ + "norm.weight"]), V(sd[b_ + "norm.bias"])),
+                w1=W(sd[b_ + "pwconv1.weight"], ddt), b1=V(sd[b_ + "pwconv1.bias"]),
+                w2=W(sd[b_ + "pwconv2.weight"], ddt), b2=V(sd[b_ + "pwconv2.bias"]), g=V(sd[b_ + "gamma"])))
+        P.vfin = (V(sd[p + "final_layer_norm.weight"]), V(sd[p + "final_layer_norm.bias"]))
+        P.hw, P.hb = W(sd["vocos.head.out.weight"], ddt), V(sd["vocos.head.out.bias"])
+        win = sd["vocos.head.istft.window"].float()
+        P.idft = W(spec.idft_basis(640, win, 648), ddt)                      # [640][648]
+        P.wsq = V(win.square())
+        torch.cuda.synchronize(dev)
+        return P
+
+    # --------------------------------------------------------- sub-graphs
+    def _cast(self, x, dt):
+        return ops.cast_bf16(x) if (dt == torch.bfloat16 and x.dtype != dt) else x
+
+    def _transformer(self, h, lens, B, T, layers, H, dt):
+        """12 x OmniWhisperTransformerLayer (modules.py:214-232). h: [B*T, D] f32 residual stream (updated in place)."""
+        D = h.shape[-1]
+        M = B * T
+        for L in layers:
+            x = ops.layernorm(h, L.ln1[0], L.ln1[1], 1e-5, B=B, t_in=T, C_=D, out_dtype=dt)
+            qkv = ops.gemm(x, L.wqkv, M, 3 * D, D, lda=D, bias=L.bqkv, out_dtype=dt)
+            a = ops.attention(qkv, lens, B, T, H)
+            ops.gemm(a, L.wo, M, D, D, lda=D, bias=L.bo, residual=h, out=h)
+            x = ops.layernorm(h, L.ln2[0], L.ln2[1], 1e-5, B=B, t_in=T, C_=D, out_dtype=dt)
+            F_ = L.w1.shape[0]
+            f = ops.gemm(x, L.w1, M, F_, D, lda=D, bias=L.b1, act=ops.ACT_GELU, out_dtype=dt)
+            ops.gemm(f, L.w2, M, D, F_, lda=F_, bias=L.b2, residual=h, out=h)
+        return h
+
+    def _res_units(self, h, units, B, T, C, dt):
+        """3 x ResidualUnit (modules.py:37-49). h: [B*T, C] f32, updated in place."""
+        M = B * T
+        for u in units:
+            y = ops.snake_aa(h, u["a0"], u["b0"], u["f0"], B=B, T=T, C_=C, out_dtype=dt)
+            y = ops.gemm(y, u["w1"], M, C, C, lda=C, ldw=7 * C, bias=u["c1"], taps=7, dil=u["dil"], pad=3 * u["dil"],
+                         t_in=T, t_out=T)
+            y = ops.snake_aa(y, u["a2"], u["b2"], u["f2"], B=B, T=T, C_=C, out_dtype=dt)
+            ops.gemm(y, u["w3"], M, C, C, lda=C, bias=u["c3"], residual=h, out=h)
+        return h
+
+    def _logmel(self, wav, n_dev, n_host, P):
+        """Whisper log-mel of the valid frames (+2 halo) on the zero-extended, reflect-padded signal
+        (feature_extractor.py:86-112). wav: [B, >=max n] f32. Returns mel [B, Tm, 80] (encode dtype), Tm."""
+        B = wav.shape[0]
+        Tm = min(spec.MEL_FRAMES, max(spec.mel_len(n) for n in n_host) + 2)
+        fr = ops.mel_frames(wav, n_dev, spec.CHUNK_SAMPLES, B=B, T=Tm)
+        M = B * Tm
+        dft = ops.gemm(fr, P.dft, M, 402, 400, lda=400)
+        pw = ops.mel_power(dft, 402, M, 208)
+        mp = ops.gemm(pw, P.melw, M, P.n_mel, 208, lda=208)
+        umax = torch.full((B,), -10.0 if Tm < spec.MEL_FRAMES else float("-inf"), device=wav.device, dtype=torch.float32)
+        ops.mel_logmax(mp, P.n_mel, umax, B=B, T=Tm, n_mel=P.n_mel)
+        mel = ops.mel_final(mp, P.n_mel, umax, B=B, T=Tm, n_mel=P.n_mel, ldo=P.n_mel, out_dtype=P.edt)
+        return mel, Tm
+
+    def _encode_mel(self, mel, Tm, t_full, tok_host, P):
+        """conv stem + encoder + down-sampler on frame-major mel [B, Tm, n_mel].
+        t_full: the number of encoder tokens the reference would run (1500 for a 30 s padded call).
+        Returns z [B, Tds, lat] f32, Tds, latent lengths (host list)."""
+        B, dt, D = mel.shape[0], P.edt, P.D
+        dev = mel.device
+        Ttok = max(1, min(t_full, max(tok_host)))
+        c1 = ops.gemm(mel, P.c1w, B * Tm, D, P.n_mel, lda=P.n_mel, ldw=3 * P.n_mel, bias=P.c1b, taps=3, pad=1, t_in=Tm,
+                      t_out=Tm, out_dtype=dt)
+        h = ops.gemm(c1, P.c2w, B * Ttok, D, D, lda=D, ldw=3 * D, bias=P.c2b, taps=3, stride=2, pad=1, t_in=Tm, t_out=Ttok)
+        lens = torch.tensor(tok_host, dtype=torch.int32, device=dev)
+        self._transformer(h, lens, B, Ttok, P.enc_layers, P.He, dt)
+        s = P.stack
+        tds_full = spec.cdiv(t_full, s)
+        Tds = min(tds_full, spec.cdiv(Ttok, s) + 64)
+        hn = torch.zeros((B, Tds * s, D), device=dev, dtype=dt)  # encoder output is exactly zero beyond each length
+        ops.layernorm(h, P.enc_ln[0], P.enc_ln[1], 1e-5, B=B, t_in=Ttok, t_out=Tds * s, C_=D, lens=lens, out=hn)
+        hd = ops.gemm(hn, P.inw, B * Tds, P.hid, s * D, lda=s * D, bias=P.inb)
+        self._res_units(hd, P.down_units, B, Tds, P.hid, dt)
+        z = ops.gemm(self._cast(hd, dt), P.tlw, B * Tds, P.lat, P.hid, lda=P.hid, bias=P.tlb)
+        return z.view(B, Tds, P.lat), Tds, [spec.cdiv(t, s) for t in tok_host]
+
+    def _decode_latent(self, zq, lat_host, B, T, P):
+        """up-sampler + decoder + Vocos on zq [B, T, lat] f32 (already masked). Returns wav [B, T*1280] f32."""
+        dt, dev = P.ddt, zq.device
+        s, D = P.stack, P.Dd
+        h = ops.gemm(self._cast(zq, dt), P.flw, B * T, P.uhid, P.lat, lda=P.lat, bias=P.flb)
+        self._res_units(h, P.up_units, B, T, P.uhid, dt)
+        # to_stacked with re-ordered rows: [B*T, s*D] is the un-stacked [B, s*T, D] token stream
+        x = ops.gemm(self._cast(h, dt), P.tsw, B * T, s * D, P.uhid, lda=P.uhid, bias=P.tsb)
+        Tt = s * T
+        x = x.view(B * Tt, D)
+        lens = torch.tensor([l * s for l in lat_host], dtype=torch.int32, device=dev)
+        self._transformer(x, lens, B, Tt, P.dec_layers, P.Hd, dt)
+        hn = ops.layernorm(x, P.dec_ln[0], P.dec_ln[1], 1e-5, B=B, t_in=Tt, C_=D, lens=lens, out_dtype=dt)
+        y3 = ops.gemm(hn, P.d1w, B * Tt, 3 * D, D, lda=D)
+        Tv = 2 * Tt
+        d1 = ops.deconv_col2im(y3, P.d1b, B=B, T=Tt, C_=D, s=2, t_out=Tv + 1, out_dtype=dt)
+        mel = ops.gemm(d1, P.d2w, B * Tv, P.vin, D, lda=D, ldw=3 * D, bias=P.d2b, taps=3, pad=2, t_in=Tv + 1, t_out=Tv,
+                       out_dtype=dt)
+        return self._vocos(mel, B, Tv, P)
+
+    def _vocos(self, mel, B, Tv, P):
+        """Vocos backbone + ISTFT head (modules.py:1492-1504, 1229-1248, 1053-1082, 831-886). mel [B, Tv, 80]."""
+        dt, C, M = P.ddt, P.vdim, B * Tv
+        x = ops.gemm(mel, P.emw, M, C, P.vin, lda=P.vin, ldw=7 * P.vin, bias=P.emb, taps=7, pad=3, t_in=Tv, t_out=Tv)
+        x = ops.layernorm(x, P.vnorm[0], P.vnorm[1], 1e-6, B=B, t_in=Tv, C_=C)
+        for blk in P.blocks:
+            y = ops.dwconv7_ln(x, blk["dw"], blk["db"], blk["ln"][0], blk["ln"][1], 1e-6, B=B, T=Tv, C_=C, out_dtype=dt)
+            y = ops.gemm(y, blk["w1"], M, P.vint, C, lda=C, bias=blk["b1"], act=ops.ACT_GELU, out_dtype=dt)
+            ops.gemm(y, blk["w2"], M, C, P.vint, lda=P.vint, bias=blk["b2"], gamma=blk["g"], residual=x, out=x)
+        hn = ops.layernorm(x, P.vfin[0], P.vfin[1], 1e-6, B=B, t_in=Tv, C_=C, out_dtype=dt)
+        ho = ops.gemm(hn, P.hw, M, 642, C, lda=C, bias=P.hb)
+        sp = ops.istft_spec(ho, 642, M, 648, out_dtype=dt)
+        fr = ops.gemm(sp, P.idft, M, 640, 648, lda=648)
+        return ops.istft_ola(fr, P.wsq, B=B, T=Tv)
+
+    # ------------------------------------------------- reference entry points
+    @torch.inference_mode()
+    def inference_tokenize(self, x, input_lengths):
+        """model.py:167-210. x (B, 1, T<=480000) on the device, input_lengths (B,).
+        Returns zq (B, D, 375), codes (G, B, 375) int32, codes_lengths (B,) int64."""
+        P = self._packed()
+        n_host = [min(int(v), spec.CHUNK_SAMPLES) for v in (input_lengths.tolist() if torch.is_tensor(input_lengths) else input_lengths)]
+        B = x.shape[0]
+        wav = x.reshape(B, -1).to(torch.float32)
+        if wav.stride(-1) != 1:
+            wav = wav.contiguous()
+        dev = wav.device
+        n_dev = torch.tensor(n_host, dtype=torch.int32, device=dev)
+        mel, Tm = self._logmel(wav, n_dev, n_host, P)
+        tok = [spec.token_len(n) for n in n_host]
+        z, Tds, lat = self._encode_mel(mel, Tm, spec.MEL_FRAMES // 2, tok, P)
+        t_pad = spec.cdiv(spec.MEL_FRAMES // 2, P.stack)  # 375: the reference always returns the padded length
+        lat_dev = torch.tensor(lat, dtype=torch.int32, device=dev)
+        zq, codes = ops.fsq_encode(z, P.lat, lat_dev, P.fsq, B=B, T=Tds, t_pad=t_pad, G=self.num_groups)
+        return {"zq": zq.transpose(1, 2), "codes": codes, "codes_lengths": lat_dev.long()}
+
+    @torch.inference_mode()
+    def inference_detokenize(self, codes, codes_lengths):
+        """model.py:212-242. codes (G, B, T) integer, codes_lengths (B,). Returns y (B, 1, T*1280), output_length."""
+        P = self._packed()
+        G, B, T = codes.shape
+        lat = [int(v) for v in (codes_lengths.tolist() if torch.is_tensor(codes_lengths) else codes_lengths)]
+        dev = codes.device
+        lat_dev = torch.tensor(lat, dtype=torch.int32, device=dev)
+        zq = ops.fsq_decode(codes.to(torch.int64).contiguous(), lat_dev, B=B, T=T, G=G)
+        wav = self._decode_latent(zq, lat, B, T, P)
+        return {"y": wav[:, None, :], "output_length": lat_dev.long() * self.decoder_upsample_rate}
+
+    @torch.inference_mode()
+    def encode(self, wav_list, overlap_seconds=10, device=torch.device("cuda")):
+        """model.py:244-308: 30 s windows every (30 - overlap) s, keep the first 250 codes of each window,
+        concatenate, trim to len // 1280.  Returns {"codes_list": [IntTensor(G, T_i)]}."""
+        sr, rate = self.input_sample_rate, self.encoder_downsample_rate
+        chunk = int(self.max_audio_seconds * sr)
+        dur = int((self.max_audio_seconds - overlap_seconds) * sr)
+        keep = dur // rate
+        B = len(wav_list)
+        if B == 0:
+            return {"codes_list": []}
+        n = [int(w.shape[-1]) if w.dim() else 0 for w in wav_list]
+        L = max(n)
+        dev = self._buffers_device() if device is None else torch.device(device)
+        wav = torch.zeros(B, max(L, 1), device=dev)
+        for i, w in enumerate(wav_list):
+            wav[i, : n[i]] = w.reshape(-1)
+        parts = []
+        for c in range(spec.cdiv(L, dur) if L else 0):
+            s0, e0 = c * dur, min(c * dur + chunk, L)
+            cl = [min(max(v - s0, 0), e0 - s0) for v in n]
+            if max(cl) == 0:
+                continue
+            r = self.inference_tokenize(wav[:, None, s0:e0], cl)
+            # codes beyond an utterance's length are already zero (FSQ kernel masks them, quantizer.py:193-196);
+            # keeping the first `keep` frames of every window reproduces model.py:291-297 without the copy loop
+            parts.append(r["codes"][:, :, :keep])
+        if not parts:
+            return {"codes_list": [torch.zeros(self.num_groups, 0, device=dev, dtype=torch.long) for _ in range(B)]}
+        allc = torch.cat(parts, dim=-1) if len(parts) > 1 else parts[0]
+        return {"codes_list": [allc[:, i, : n[i] // rate] for i in range(B)]}
+
+    @torch.inference_mode()
+    def decode(self, codes_list, overlap_seconds=10, device=torch.device("cuda")):
+        """model.py:310-373: 375-code windows every 250 codes, keep the first 320000 samples of each,
+        concatenate, trim to T_i * 1280.  Returns {"syn_wav_list": [FloatTensor(T_i * 1280)]}."""
+        sr, rate = self.input_sample_rate, self.encoder_downsample_rate
+        win = int(self.max_audio_seconds * sr // rate)
+        step = int((self.max_audio_seconds - overlap_seconds) * sr // rate)
+        keep = step * self.decoder_upsample_rate
+        B = len(codes_list)
+        if B == 0:
+            return {"syn_wav_list": []}
+        n = [int(c.shape[-1]) for c in codes_list]
+        L = max(n)
+        dev = self._buffers_device() if device is None else torch.device(device)
+        if L == 0:
+            return {"syn_wav_list": [torch.zeros(0, device=dev) for _ in range(B)]}
+        codes = torch.zeros(self.num_groups, B, L, device=dev, dtype=torch.long)
+        for i, c in enumerate(codes_list):
+            codes[:, i, : n[i]] = c.to(dev)
+        parts = []
+        for c in range(spec.cdiv(L, step)):
+            s0, e0 = c * step, min(c * step + win, L)
+            cl = [min(max(v - s0, 0), e0 - s0) for v in n]
+            if max(cl) == 0:
+                continue
+            r = self.inference_detokenize(codes[:, :, s0:e0].contiguous(), cl)
+            # samples beyond an utterance's valid length fall after its final trim (n_i * 1280), so the
+            # zero-fill of model.py:356-360 is unobservable: keep the first `keep` samples of each window
+            parts.append(r["y"][:, 0, :keep])
+        wav = torch.cat(parts, dim=-1) if len(parts) > 1 else parts[0]
+        return {"syn_wav_list": [wav[i, : n[i] * self.decoder_upsample_rate] for i in range(B)]}
+
+    @torch.inference_mode()
+    def forward(self, batch):
+        """model.py:112-165: mel (B, n_mel, T) + mel_lens -> {'reconstructed_audio' (B,1,T_audio), 'audio_lengths'}.
+        No 30 s padding and no chunking; the un-masked up-sampler sees the whole padded length."""
+        P = self._packed()
+        mel_in, ml = batch["mel_features"], batch["mel_lens"]
+        B, _, T = mel_in.shape
+        ml_host = [int(v) for v in ml.tolist()]
+        mel = mel_in.to(torch.float32).transpose(1, 2).contiguous()
+        mel = self._cast(mel, P.edt)
+        t_full = (T - 1) // 2 + 1  # Conv1d(k3, s2, p1) output length
+        tok = [m // 2 for m in ml_host]
+        # the trimmed stem needs frames up to 2*max(tok): the given T is the true right boundary
+        z, Tds, lat = self._encode_mel(mel, T, t_full, tok, P)
+        dev = mel.device
+        t_lat = spec.cdiv(t_full, P.stack)
+        lat_dev = torch.tensor(lat, dtype=torch.int32, device=dev)
+        zq, _ = ops.fsq_encode(z, P.lat, lat_dev, P.fsq, B=B, T=Tds, t_pad=t_lat, G=self.num_groups)
+        wav = self._decode_latent(zq, lat, B, t_lat, P)
+        return {"reconstructed_audio": wav[:, None, :],
+                "audio_lengths": lat_dev.long() * (P.stack * 2 * self.generator_params["vocos"]["hop_size"])}

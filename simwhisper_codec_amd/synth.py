@@ -180,6 +180,8 @@ def synth_audio(n_samples, index=0, seed=1234, kind="noise"):
     noise : 0.1 * sqrt(3) * U(-1, 1)  (std 0.1, the survey's white-noise level)
     speech: five harmonics of a gliding f0 under a slow envelope, plus a little noise.
     """
+    if kind == "zero":
+        return torch.zeros(n_samples)
     u = _uniform(f"audio/{kind}/{index}", n_samples, seed)
     if kind == "noise":
         return torch.from_numpy(u * np.float32(0.1 * math.sqrt(3.0)))
