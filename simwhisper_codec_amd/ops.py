@@ -12,6 +12,10 @@ from ._lib import ACT_GELU, ACT_NONE, BF16, F32  # noqa: F401
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
+# Optional per-launch timing hook (bench.py): an object with begin(kind, work) / end(), called
+# around every swc_gemm launch on the launching stream.  None in normal operation.
+PROFILER = None
+
 
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -55,7 +59,12 @@ def gemm(A, W, M, N, K, *, out=None, out_dtype=None, lda=None, ldw=None, ldc=Non
     if M == 0:
         return out
     a.a_dtype, a.c_dtype, a.act = _DT[A.dtype], _DT[out.dtype], act
+    prof = PROFILER
+    if prof is not None:
+        prof.begin("gemm_bf16" if A.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * taps)
     _lib.check(lib.swc_gemm(C.byref(a), _stream()), "swc_gemm")
+    if prof is not None:
+        prof.end()
     return out
 
 
