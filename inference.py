@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""Batch codec round trip over a directory of audio files — the reference's CLI surface
+(inference.py:12-21 there): same flags, same outputs (`<output_dir>/<basename>.wav`, PCM16).
+
+    python inference.py --config_path ./config/SimWhisperCodec.yaml \\
+        --checkpoint_path ./weights/SimWhisperCodec.pt --device cuda \\
+        --batch_size 8 --input_dir input_wavs --output_dir output_wavs
+
+Differences on purpose: `--device` is passed on to encode()/decode() (the reference forgets to),
+file loading for batch i+1 and saving of batch i-1 overlap the GPU work of batch i, and
+`--precision` / `--synthetic_checkpoint` exist because the trained weights cannot be fetched offline.
+"""
+import argparse
+import logging
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from audiocodec.model import AudioCodec  # noqa: E402
+from simwhisper_codec_amd.wavio import find_audio_files, load_audio, save_audio  # noqa: E402
+
+
+def set_logging(level="INFO"):
+    rank = os.environ.get("RANK", 0)
+    logging.basicConfig(level=getattr(logging, str(level).upper(), logging.INFO), stream=sys.stdout,
+                        format=f"%(asctime)s [RANK {rank}] (%(module)s:%(lineno)d) %(levelname)s : %(message)s")
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--config_path", type=str, default="./config/SimWhisperCodec.yaml")
+    p.add_argument("--checkpoint_path", type=str, default="./weights/SimWhisperCodec.pt")
+    p.add_argument("--device", type=str, default="cuda")
+    p.add_argument("--batch_size", type=int, default=8)
+    p.add_argument("--input_dir", type=str, default="input_wavs")
+    p.add_argument("--output_dir", type=str, default="output_wavs")
+    p.add_argument("--precision", type=str, default="mixed", choices=["fp32", "mixed", "bf16"])
+    p.add_argument("--synthetic_checkpoint", action="store_true",
+                   help="ignore --checkpoint_path and use the closed-form synthetic weights (offline testing)")
+    return p
+
+
+def load_model(args, device):
+    if args.synthetic_checkpoint:
+        import yaml
+        from simwhisper_codec_amd import synth
+        gp = yaml.safe_load(open(args.config_path))["generator_params"]
+        model = AudioCodec(gp)
+        model.load_state_dict(synth.synth_state_dict(gp), strict=True)
+    else:
+        model = AudioCodec.load_from_checkpoint(config_path=args.config_path, ckpt_path=args.checkpoint_path)
+    model.precision = args.precision
+    return model.to(device).eval()
+
+
+def main(argv=None):
+    set_logging()
+    args = build_parser().parse_args(argv)
+    device = torch.device(args.device)
+    generator = load_model(args, device)
+    audio_paths = find_audio_files(input_dir=args.input_dir)
+    os.makedirs(args.output_dir, exist_ok=True)
+    logging.info(f"Processing {len(audio_paths)} audio files, output will be saved to {args.output_dir}")
+    bs = args.batch_size
+    batches = [audio_paths[i:i + bs] for i in range(0, len(audio_paths), bs)]
+
+    def load(paths):
+        return [load_audio(p, target_sample_rate=generator.input_sample_rate).reshape(-1).pin_memory()
+                if device.type == "cuda" else load_audio(p, target_sample_rate=generator.input_sample_rate).reshape(-1)
+                for p in paths]
+
+    def save(paths, wavs):
+        for path, wav in zip(paths, wavs):
+            out = os.path.join(args.output_dir, os.path.splitext(os.path.basename(path))[0] + ".wav")
+            save_audio(out, wav.reshape(1, -1), sample_rate=generator.output_sample_rate)
+
+    total_audio, t0 = 0.0, time.perf_counter()
+    with ThreadPoolExecutor(max_workers=2) as pool, torch.no_grad():
+        nxt = pool.submit(load, batches[0]) if batches else None
+        pending = None
+        for bi, paths in enumerate(batches):
+            logging.info(f"Processing batch {bi + 1}/{len(batches)}, files: {paths}")
+            cpu_wavs = nxt.result()
+            nxt = pool.submit(load, batches[bi + 1]) if bi + 1 < len(batches) else None
+            wav_list = [w.to(device, non_blocking=True) for w in cpu_wavs]
+            logging.info(f"Successfully loaded {len(wav_list)} audio files with lengths {[len(w) for w in wav_list]} samples")
+            codes_list = generator.encode(wav_list, overlap_seconds=10, device=device)["codes_list"]
+            logging.info(f"Encoding completed, code lengths: {[c.shape[-1] for c in codes_list]}")
+            syn = generator.decode(codes_list, overlap_seconds=10, device=device)["syn_wav_list"]
+            logging.info(f"Decoding completed, generated waveform lengths: {[len(w) for w in syn]} samples")
+            host = [w.cpu() for w in syn]
+            total_audio += sum(len(w) for w in host) / generator.output_sample_rate
+            if pending is not None:
+                pending.result()
+            pending = pool.submit(save, paths, host)
+        if pending is not None:
+            pending.result()
+    dt = time.perf_counter() - t0
+    logging.info(f"All audio processing completed: {total_audio:.1f} s of audio in {dt:.2f} s "
+                 f"({total_audio / max(dt, 1e-9):.1f} x real time incl. file IO)")
+
+
+if __name__ == "__main__":
+    main()

@@ -432,9 +432,12 @@ class AudioCodec(nn.Module):
         return {"codes_list": [allc[:, i, : n[i] // rate] for i in range(B)]}
 
     @torch.inference_mode()
-    def decode(self, codes_list, overlap_seconds=10, device=torch.device("cuda")):
+    def decode(self, codes_list, overlap_seconds=10, device=torch.device("cuda"), pad_to_length=None):
         """model.py:310-373: 375-code windows every 250 codes, keep the first 320000 samples of each,
-        concatenate, trim to T_i * 1280.  Returns {"syn_wav_list": [FloatTensor(T_i * 1280)]}."""
+        concatenate, trim to T_i * 1280.  Returns {"syn_wav_list": [FloatTensor(T_i * 1280)]}.
+        pad_to_length (extension): pad the batch to at least this many code frames — a shard of a larger
+        batch passes the global maximum so that its results equal the un-sharded call (the reference's
+        up-sampler / Vocos are not masked, so outputs depend on the padded batch length)."""
         sr, rate = self.input_sample_rate, self.encoder_downsample_rate
         win = int(self.max_audio_seconds * sr // rate)
         step = int((self.max_audio_seconds - overlap_seconds) * sr // rate)
@@ -443,7 +446,7 @@ class AudioCodec(nn.Module):
         if B == 0:
             return {"syn_wav_list": []}
         n = [int(c.shape[-1]) for c in codes_list]
-        L = max(n)
+        L = max(max(n), int(pad_to_length or 0))
         dev = self._buffers_device() if device is None else torch.device(device)
         if L == 0:
             return {"syn_wav_list": [torch.zeros(0, device=dev) for _ in range(B)]}

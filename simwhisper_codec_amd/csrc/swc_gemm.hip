@@ -21,10 +21,23 @@ constexpr int ROW_BYTES = 128;            // bytes of K per LDS row per slice
 constexpr int TILE_BYTES = BM * ROW_BYTES;  // 16 KiB per operand per stage
 constexpr int NTHREADS = 256;
 
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+// 16 bytes per lane, global -> LDS without a VGPR round trip.  `lds_base` must be wave-uniform:
+// the hardware writes lane l at lds_base + 16 * l.
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gsrc,
+        (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 1) ^ ((row >> 4) << 1)) & 7; }
+
 __device__ __forceinline__ int lds_off(int row, int chunk) {
-    // conflict-free for the 16-lane groups of ds_read_b128: rows r, r+2, .. share a
-    // 256-byte bank row, so spread the chunk index by (row >> 1).
-    return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4);
+    // conflict-free for the 16-lane groups of ds_read_b128, both for 16 consecutive rows (activation
+    // fragments) and for the permuted weight rows {16a + 4j + b} of the transposed-product epilogue
+    // (checked exhaustively over the four lane groups): rows r, r+2 share a 256-byte bank row.
+    return row * ROW_BYTES + ((chunk ^ swz(row)) << 4);
 }
 
 struct GemmP {
@@ -87,42 +100,35 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmP p) {
         w_rowoff[i] = (long)(w_rowok[i] ? n : 0) * p.ldw;
     }
 
-    uint4 ra[4], rb[4];
-    auto load_slice = [&](int kt) {
+    // Direct global->LDS staging (global_load_lds_dwordx4): one wave-instruction fills 8 LDS rows
+    // (1 KiB, lane-linear), so the XOR swizzle lives on the SOURCE address: the lane that lands on
+    // chunk position p of row r fetches logical chunk p ^ ((r >> 1) & 7).  Lanes whose row / tap /
+    // K-chunk is out of range fetch a 16-byte device zero page instead (no zero-fill path exists).
+    int a_chunk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (tid >> 3) + 32 * i;
+        a_chunk[i] = ld_chunk ^ swz(row);
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto stage_slice = [&](int kt, int stage) {
         const int tap = kt / p.kc_per_tap;
         const int kc = kt - tap * p.kc_per_tap;
-        const int k0 = kc * BK + ld_chunk * EPC;
-        const bool kok = k0 < p.K;
         const int shift = tap * p.dil - p.pad;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ts = a_t[i] * p.stride + shift;
-            const bool ok = a_rowok[i] && kok && ts >= 0 && ts < p.t_in;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const long off = ((long)a_b[i] * p.t_in + ts) * p.lda + k0;
-                v = *reinterpret_cast<const uint4*>(p.A + off * ES);
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (w_rowok[i] && kok) {
-                const long off = w_rowoff[i] + (long)tap * p.K + k0;
-                v = *reinterpret_cast<const uint4*>(p.W + off * ES);
-            }
-            rb[i] = v;
-        }
-    };
-    auto store_slice = [&](int stage) {
         char* sa = smem + stage * 2 * TILE_BYTES;
         char* sb = sa + TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int row = (tid >> 3) + 32 * i;
-            *reinterpret_cast<uint4*>(sa + lds_off(row, ld_chunk)) = ra[i];
-            *reinterpret_cast<uint4*>(sb + lds_off(row, ld_chunk)) = rb[i];
+            const int k0 = kc * BK + a_chunk[i] * EPC;
+            const bool kok = k0 < p.K;
+            const int ts = a_t[i] * p.stride + shift;
+            const bool ok = a_rowok[i] && kok && ts >= 0 && ts < p.t_in;
+            const char* src = reinterpret_cast<const char*>(g_zero16);
+            if (ok) src = p.A + (((long)a_b[i] * p.t_in + ts) * p.lda + k0) * ES;
+            glds16(src, sa + (32 * i + 8 * wave_u) * ROW_BYTES);
+            const char* srcw = reinterpret_cast<const char*>(g_zero16);
+            if (w_rowok[i] && kok) srcw = p.W + (w_rowoff[i] + (long)tap * p.K + k0) * ES;
+            glds16(srcw, sb + (32 * i + 8 * wave_u) * ROW_BYTES);
         }
     };
 
@@ -133,14 +139,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmP p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nkt = p.taps * p.kc_per_tap;
-    load_slice(0);
-    store_slice(0);
-    __syncthreads();
+    stage_slice(0, 0);
+    __syncthreads();  // drains vmcnt (the LDS-DMA) before the barrier
 
     const int fr = lane & 15, fh = lane >> 4;
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nkt) load_slice(kt + 1);
+        if (kt + 1 < nkt) stage_slice(kt + 1, cur ^ 1);
         const char* sa = smem + cur * 2 * TILE_BYTES;
         const char* sb = sa + TILE_BYTES;
 #pragma unroll
@@ -150,7 +155,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmP p) {
             for (int i = 0; i < 4; ++i) {
                 const int ra_row = wr * 64 + i * 16 + fr;
                 fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off(ra_row, fh + 4 * g));
-                const int rb_row = wc * 64 + i * 16 + fr;
+                // weight rows are taken in the order {16a + 4i + b}: with the weight fragment as the
+                // MFMA's row operand, lane (fr, fh) then owns 16 CONTIGUOUS output columns 16fh + 4i + e
+                const int rb_row = wc * 64 + 16 * (fr >> 2) + 4 * i + (fr & 3);
                 fb[i] = *reinterpret_cast<const uint4*>(sb + lds_off(rb_row, fh + 4 * g));
             }
             if constexpr (BF16) {
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            *reinterpret_cast<bf16x8*>(&fa[i]), *reinterpret_cast<bf16x8*>(&fb[j]),
+                            *reinterpret_cast<bf16x8*>(&fb[j]), *reinterpret_cast<bf16x8*>(&fa[i]),
                             acc[i][j], 0, 0, 0);
             } else {
 #pragma unroll
@@ -172,35 +179,77 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmP p) {
                             const float bv =
                                 __uint_as_float(reinterpret_cast<const unsigned*>(&fb[j])[e]);
                             acc[i][j] =
-                                __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
+                                __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
                         }
                     }
                 }
             }
         }
-        if (kt + 1 < nkt) store_slice(cur ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: C/D map col = lane & 15, row = (lane >> 4) * 4 + reg
+    // ---- epilogue.  Transposed product: D[n][m], so lane (fr, fh) holds, for row m = 16i + fr,
+    // the 16 contiguous columns 16fh + 4j + e (j = 0..3, e = 0..3) of its wave's 64-column slab.
     OutT* C = reinterpret_cast<OutT*>(p.C);
+    const int col0 = bn + wc * 64 + 16 * fh;
+    const bool vec_ok = (col0 + 16 <= p.N) && ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) &&
+                        ((reinterpret_cast<uintptr_t>(p.gamma) & 15) == 0);
+    float bv[16], gv[16];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = bn + wc * 64 + j * 16 + fr;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
-        const float gv = p.gamma ? p.gamma[col] : 1.f;
+    for (int c = 0; c < 16; ++c) {
+        const int col = col0 + c;
+        bv[c] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+        gv[c] = (p.gamma && col < p.N) ? p.gamma[col] : 1.f;
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {
+        const int row = bm + wr * 64 + i * 16 + fr;
+        if (row >= p.M) continue;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int row = bm + wr * 64 + i * 16 + fh * 4 + e;
-                if (row >= p.M) continue;
-                float v = acc[i][j][e] + bv;
-                if (p.act == SWC_ACT_GELU) v = gelu_erf(v);
-                v *= gv;
-                if (p.residual) v += p.residual[(long)row * p.ldr + col];
-                store_out<OutT>(C + (long)row * p.ldc + col, v);
+                float x = acc[i][j][e] + bv[4 * j + e];
+                if (p.act == SWC_ACT_GELU) x = gelu_erf(x);
+                v[4 * j + e] = x * gv[4 * j + e];
+            }
+        if (vec_ok) {
+            if (p.residual) {
+                const float4* rp = reinterpret_cast<const float4*>(p.residual + (long)row * p.ldr + col0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 r4 = rp[j];
+                    v[4 * j] += r4.x; v[4 * j + 1] += r4.y; v[4 * j + 2] += r4.z; v[4 * j + 3] += r4.w;
+                }
+            }
+            OutT* cp = C + (long)row * p.ldc + col0;
+            if constexpr (sizeof(OutT) == 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    reinterpret_cast<float4*>(cp)[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint4 u;
+                    u.x = (unsigned)f32_to_bf16(v[8 * j + 0]) | ((unsigned)f32_to_bf16(v[8 * j + 1]) << 16);
+                    u.y = (unsigned)f32_to_bf16(v[8 * j + 2]) | ((unsigned)f32_to_bf16(v[8 * j + 3]) << 16);
+                    u.z = (unsigned)f32_to_bf16(v[8 * j + 4]) | ((unsigned)f32_to_bf16(v[8 * j + 5]) << 16);
+                    u.w = (unsigned)f32_to_bf16(v[8 * j + 6]) | ((unsigned)f32_to_bf16(v[8 * j + 7]) << 16);
+                    reinterpret_cast<uint4*>(cp)[j] = u;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int col = col0 + c;
+                if (col >= p.N) continue;
+                float x = v[c];
+                if (p.residual) x += p.residual[(long)row * p.ldr + col];
+                store_out<OutT>(C + (long)row * p.ldc + col, x);
             }
         }
     }

@@ -1,0 +1,84 @@
+"""world_size-2 (and 3) `gloo` tests of the data-parallel wrapper: sharded == un-sharded, incl. the
+T_max rule of decode.  The codec here is a small CPU stand-in with the reference's T_max dependence
+(the HIP codec needs a GPU); the real codec is covered by tests/test_parity_gpu.py."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from simwhisper_codec_amd.dist import DataParallelCodec, partition
+
+
+class FakeCodec:
+    """Deterministic per-utterance 'codec' whose decode depends on the padded batch length."""
+    num_groups = 8
+    encoder_downsample_rate = 1280
+    decoder_upsample_rate = 1280
+
+    def encode(self, wav_list, overlap_seconds=10, device=None):
+        out = []
+        for w in wav_list:
+            T = w.shape[-1] // 1280
+            fr = w[: T * 1280].view(T, 1280)
+            base = (fr.abs().sum(1) * 1000).long() % 2016
+            out.append(torch.stack([(base + g) % 2016 for g in range(8)]).to(torch.int32))
+        return {"codes_list": out}
+
+    def decode(self, codes_list, overlap_seconds=10, device=None, pad_to_length=None):
+        L = max(max(c.shape[-1] for c in codes_list), int(pad_to_length or 0))
+        out = []
+        for c in codes_list:
+            v = c.float().mean(0)  # (T,)
+            out.append((v[:, None] * torch.linspace(0, 1, 1280)[None, :] + 0.001 * L).reshape(-1))
+        return {"syn_wav_list": out}
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, lens, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        codec = FakeCodec()
+        dp = DataParallelCodec(codec, "cpu")
+        g = torch.Generator().manual_seed(0)
+        wavs = [torch.randn(n, generator=g) for n in lens] if rank == 0 else None
+        enc = dp.encode(wavs)
+        dec = dp.decode(enc["codes_list"] if rank == 0 else None)
+        if rank == 0:
+            want_c = codec.encode(wavs)["codes_list"]
+            want_w = codec.decode(want_c)["syn_wav_list"]
+            ok = all(torch.equal(a, b) for a, b in zip(enc["codes_list"], want_c)) and len(enc["codes_list"]) == len(lens)
+            ok = ok and all(torch.equal(a, b) for a, b in zip(dec["syn_wav_list"], want_w))
+            ret.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lens", [(2, [5000, 12800, 3000, 40000, 1280]), (3, [2560, 2560]), (2, [1000])])
+def test_sharded_equals_unsharded(world, lens):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lens, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
+
+
+def test_partition_properties():
+    for w, n in [([1] * 10, 3), ([5, 1, 1, 1, 9, 2], 4), ([3], 4), ([], 2), ([1, 1], 8)]:
+        parts = partition(w, n)
+        assert len(parts) == n and parts[0][0] == 0 and parts[-1][1] == len(w)
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(n - 1))
+        assert all(a <= b for a, b in parts)
+    parts = partition([1] * 256, 8)
+    assert [b - a for a, b in parts] == [32] * 8

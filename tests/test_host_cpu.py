@@ -1,0 +1,164 @@
+"""CPU-side checks: the C-ABI library loads and exports what include/swc.h declares, the host
+logic (shapes, length laws, constant tables, checkpoint surface, file IO, CLI flags) is right.
+No kernel is launched here."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from common import PARAMS, ROOT, golden, state_dict
+
+
+def test_library_exports_every_declared_symbol():
+    from simwhisper_codec_amd import _lib, build
+    build.build_library()
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "swc.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(swc_\w+)\s*\(", hdr, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.swc_version() >= 100
+
+
+def test_arg_checks_without_gpu():
+    """argument validation happens before any launch, so it is testable without a device."""
+    import ctypes as C
+    from simwhisper_codec_amd import _lib
+    lib = _lib.load()
+    a = _lib.GemmArgs()
+    assert lib.swc_gemm(C.byref(a), None) == -1
+    assert b"null" in lib.swc_last_error()
+
+
+@pytest.mark.parametrize("tag", ["tiny", "real"])
+def test_state_shapes_match_checkpoint_layout(tag):
+    from simwhisper_codec_amd import spec
+    shapes = spec.state_shapes(PARAMS[tag]())
+    sd = state_dict(tag)
+    assert set(shapes) == set(sd)
+    for k, (shape, dtype) in shapes.items():
+        assert tuple(sd[k].shape) == shape and sd[k].dtype == dtype, k
+    if tag == "real":
+        assert len(shapes) == 711
+
+
+def test_mel_filters_match_transformers_and_reference():
+    from simwhisper_codec_amd import spec
+    from transformers.audio_utils import mel_filter_bank
+    want = mel_filter_bank(num_frequency_bins=201, num_mel_filters=80, min_frequency=0.0, max_frequency=8000.0,
+                           sampling_rate=16000, norm="slaney", mel_scale="slaney")
+    got = spec.slaney_mel_filters()
+    assert np.abs(got - want).max() < 1e-12
+    assert np.abs(got - golden("real", "facts")["mel_filters"]).max() < 1e-12
+
+
+def test_dft_basis_is_torch_stft():
+    from simwhisper_codec_amd import spec
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4000, generator=g, dtype=torch.float64)
+    st = torch.stft(x, 400, 160, window=torch.hann_window(400, dtype=torch.float64), return_complex=True)  # (2,201,T)
+    xp = torch.nn.functional.pad(x[:, None], (200, 200), mode="reflect")[:, 0]
+    fr = xp.unfold(1, 400, 160)  # (2,T,400)
+    out = fr @ spec.dft_basis_400().double().T  # (2,T,402)
+    assert (out[..., :201].transpose(1, 2) - st.real).abs().max() < 1e-5
+    assert (out[..., 201:].transpose(1, 2).abs() - st.imag.abs()).abs().max() < 1e-5
+
+
+def test_idft_basis_is_irfft_times_window():
+    from simwhisper_codec_amd import spec
+    g = torch.Generator().manual_seed(1)
+    re, im = torch.randn(5, 321, generator=g, dtype=torch.float64), torch.randn(5, 321, generator=g, dtype=torch.float64)
+    win = torch.hann_window(640)
+    want = torch.fft.irfft(torch.complex(re, im), 640, dim=1, norm="backward") * win.double()
+    B = spec.idft_basis(640, win, 648).double()
+    row = torch.cat([re, im, torch.zeros(5, 6, dtype=torch.float64)], 1)
+    assert (row @ B.T - want).abs().max() < 1e-7
+
+
+def test_fsq_constants_match_oracle():
+    from simwhisper_codec_amd import spec
+    from common import oracle
+    k = spec.fsq_constants([8, 7, 6, 6], 1e-3)
+    s, o, sh = oracle("tiny")._fsq_consts()
+    assert k == torch.cat([s.view(-1), o.view(-1), sh.view(-1)]).tolist()
+
+
+def test_length_laws():
+    from simwhisper_codec_amd import spec
+    for n in (0, 1, 159, 160, 161, 1279, 1280, 50000, 160000, 479999, 480000, 600000):
+        m = min(n, 480000)
+        assert spec.mel_len(n) == -(-m // 160)
+        assert spec.token_len(n) == spec.mel_len(n) // 2
+        assert spec.latent_len(n) == -(-spec.token_len(n) // 4)
+        assert spec.latent_len(n) >= n // 1280 if n <= 480000 else True
+    # docs/assets/codec length contract: 142720 samples -> 111 codes -> 142080 samples
+    assert 142720 // 1280 == 111 and 111 * 1280 == 142080
+
+
+def test_model_surface_and_checkpoint_roundtrip(tmp_path):
+    import yaml
+    from audiocodec.model import AudioCodec
+    from simwhisper_codec_amd._lib import SwcError
+    gp = PARAMS["tiny"]()
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(yaml.safe_dump({"generator_params": gp}))
+    sd = state_dict("tiny")
+    for payload, name in ((sd, "bare.pt"), ({"model": sd}, "wrapped.pt")):
+        torch.save(payload, tmp_path / name)
+        m = AudioCodec.load_from_checkpoint(str(cfg), str(tmp_path / name))
+        got = m.state_dict()
+        assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    assert (m.input_sample_rate, m.output_sample_rate, m.max_audio_seconds) == (16000, 16000, 30)
+    assert (m.encoder_downsample_rate, m.decoder_upsample_rate, m.num_groups) == (1280, 1280, 8)
+    for fn in ("encode", "decode", "inference_tokenize", "inference_detokenize", "forward", "remove_weight_norm",
+               "load_from_checkpoint"):
+        assert callable(getattr(m, fn))
+    bad = dict(sd); bad.pop("vocos.head.out.bias")
+    with pytest.raises(RuntimeError):
+        AudioCodec(gp).load_state_dict(bad, strict=True)
+    with pytest.raises(SwcError):  # no CPU fallback, and it says so
+        m.encode([torch.zeros(3000)], device=torch.device("cpu"))
+    assert m.encode([], device=torch.device("cpu")) == {"codes_list": []}
+
+
+def test_wav_io_roundtrip(tmp_path):
+    import struct
+    from simwhisper_codec_amd.wavio import find_audio_files, load_audio, save_audio
+    x = 0.5 * torch.sin(torch.arange(16000) / 7.0)
+    p = tmp_path / "sub" / "a.wav"
+    p.parent.mkdir()
+    save_audio(str(p), x.reshape(1, -1), 16000)
+    y = load_audio(str(p), 16000)
+    assert y.shape == (1, 1, 16000) and (y.reshape(-1) - x).abs().max() < 1.0 / 32767
+    assert load_audio(str(p), 8000).shape == (1, 1, 8000)
+    # stereo float32 file -> mono mean
+    st = np.stack([x.numpy(), -x.numpy() * 0.5], 1).astype("<f4").tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(st)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 3, 2, 16000, 16000 * 8, 8, 32)
+    (tmp_path / "b.wav").write_bytes(hdr + b"data" + struct.pack("<I", len(st)) + st)
+    z = load_audio(str(tmp_path / "b.wav"), 16000).reshape(-1)
+    assert (z - 0.25 * x).abs().max() < 1e-6
+    (tmp_path / "c.flac").write_bytes(b"fLaC")
+    assert [os.path.basename(f) for f in find_audio_files(str(tmp_path))] == ["b.wav", "c.flac", "a.wav"]
+    with pytest.raises(RuntimeError):
+        load_audio(str(tmp_path / "c.flac"), 16000)
+
+
+def test_cli_flags_are_the_reference_flags():
+    import inference
+    p = inference.build_parser()
+    d = vars(p.parse_args([]))
+    for k, v in {"config_path": "./config/SimWhisperCodec.yaml", "checkpoint_path": "./weights/SimWhisperCodec.pt",
+                 "device": "cuda", "batch_size": 8, "input_dir": "input_wavs", "output_dir": "output_wavs"}.items():
+        assert d[k] == v
+
+
+def test_product_never_imports_oracle():
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r); import simwhisper_codec_amd.codec, simwhisper_codec_amd.dist, "
+            "simwhisper_codec_amd.wavio, audiocodec.model; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)" % ROOT)
+    subprocess.run([sys.executable, "-c", code], check=True)

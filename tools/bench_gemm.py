@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of swc_gemm on the hot-path shapes (B=32 x 10 s): TFLOP/s per shape and dtype.
+Random operands (zero-filled data reads high on this chip), interleaved rounds, median."""
+import sys, os, time, statistics
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from simwhisper_codec_amd import ops
+
+SHAPES = [  # (name, M, N, K)
+    ("qkv      ", 16000, 2304, 768), ("out_proj ", 16000, 768, 768), ("fc1      ", 16000, 3072, 768),
+    ("fc2      ", 16000, 768, 3072), ("pwconv1  ", 32000, 4096, 512), ("pwconv2  ", 32000, 512, 4096),
+    ("head     ", 32000, 642, 512), ("idft     ", 32000, 640, 648),
+]
+
+def main():
+    dts = [torch.bfloat16, torch.float32] if len(sys.argv) < 2 else [dict(bf16=torch.bfloat16, f32=torch.float32)[sys.argv[1]]]
+    dev = "cuda"
+    for dt in dts:
+        tot_f = tot_t = 0.0
+        for name, M, N, K in SHAPES:
+            A = (torch.randn(M, K, device=dev) * 0.5).to(dt)
+            W = (torch.randn(N, K, device=dev) * 0.05).to(dt)
+            bias = torch.randn(N, device=dev)
+            out = torch.empty(M, N, device=dev, dtype=dt if dt == torch.bfloat16 else torch.float32)
+            for _ in range(3):
+                ops.gemm(A, W, M, N, K, bias=bias, out=out)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(7):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    ops.gemm(A, W, M, N, K, bias=bias, out=out)
+                e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / 5)
+            t = statistics.median(ts)
+            fl = 2.0 * M * N * K
+            tot_f += fl; tot_t += t
+            print(f"{str(dt)[6:]:9s} {name} M={M:6d} N={N:5d} K={K:5d}  {t*1e3:8.1f} us  {fl/t/1e9:8.1f} TFLOP/s", flush=True)
+        print(f"{str(dt)[6:]:9s} total {tot_f/tot_t/1e9:8.1f} TFLOP/s")
+
+if __name__ == "__main__":
+    main()
