@@ -361,8 +361,9 @@ class AudioCodec(nn.Module):
             y = ops.gemm(y, blk["w1"], M, P.vint, C, lda=C, bias=blk["b1"], act=ops.ACT_GELU, out_dtype=dt)
             ops.gemm(y, blk["w2"], M, C, P.vint, lda=P.vint, bias=blk["b2"], gamma=blk["g"], residual=x, out=x)
         hn = ops.layernorm(x, P.vfin[0], P.vfin[1], 1e-6, B=B, t_in=Tv, C_=C, out_dtype=dt)
-        ho = ops.gemm(hn, P.hw, M, 642, C, lda=C, bias=P.hb)
-        sp = ops.istft_spec(ho, 642, M, 648, out_dtype=dt)
+        ho = torch.empty((M, 648), device=mel.device, dtype=torch.float32)  # ld 648: 16-byte rows for vector stores
+        ops.gemm(hn, P.hw, M, 642, C, lda=C, bias=P.hb, out=ho, ldc=648)
+        sp = ops.istft_spec(ho, 648, M, 648, out_dtype=dt)
         fr = ops.gemm(sp, P.idft, M, 640, 648, lda=648)
         return ops.istft_ola(fr, P.wsq, B=B, T=Tv)
 

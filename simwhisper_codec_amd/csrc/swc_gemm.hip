@@ -1,44 +1,53 @@
-// swc_gemm: C = epi(A (*) W^T) on gfx950 MFMA, plain GEMM or implicit-GEMM Conv1d
-// over frame-major activations.  One 128x128 output tile per 256-thread workgroup
-// (4 waves as 2x2, 64x64 per wave = 4x4 MFMA 16x16 tiles), K walked in 128-byte
-// slices (32 f32 / 64 bf16) through a double-buffered, XOR-swizzled LDS image.
+// swc_gemm: C = epi(A (*) W^T) on gfx950 MFMA — plain GEMM or implicit-GEMM Conv1d over
+// frame-major activations.
 //
-// f32 : v_mfma_f32_16x16x4_f32  (exact f32 fma chain, the parity path)
+// One template, two geometries (WAVES_M x WAVES_N waves, each wave 16*MT x 64 outputs):
+//   128 x 128 tile, 4 waves (2x2, MT=4), 64 KiB LDS, 2 workgroups / CU   — f32 and bf16, any shape
+//   256 x 256 tile, 8 waves (2x4, MT=8), 128 KiB LDS, 1 workgroup / CU   — bf16, large M and N
+// K is walked in 128-byte slices (32 f32 / 64 bf16) through a double-buffered LDS image filled by
+// LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write).
+//
+// f32 : v_mfma_f32_16x16x4_f32   (bit-for-bit an f32 fma chain: the parity path)
 // bf16: v_mfma_f32_16x16x32_bf16 (f32 accumulate)
 //
-// Fragment addressing (both dtypes): lane l, r = l & 15, h = l >> 4 reads the 16-byte
-// chunk c = h + 4g (g = 0,1) of LDS row r.  For f32 the chunk's 4 floats are 4
-// successive MFMA k-steps (element j of every lane is k = 16g + 4h + j: a permuted but
-// complete walk of the slice); for bf16 the chunk is the 8-element operand of one
-// 16x16x32 step (k = 32g + 8h + j).
+// LDS image: row r (128 bytes) holds eight 16-byte chunks; logical chunk c sits at position
+// c ^ swz(r).  One LDS-DMA wave-instruction writes 8 rows lane-linearly, so the swizzle is applied to
+// the per-lane SOURCE address.  Fragment reads (ds_read_b128): lane (fr = l & 15, fh = l >> 4) reads
+// chunk fh + 4g of its row; for f32 the chunk's 4 floats feed 4 successive MFMA k-steps (a permuted but
+// complete walk of the slice), for bf16 the chunk is the 8-element operand of one 16x16x32 step.
+//
+// The product is computed TRANSPOSED (weight fragment = MFMA row operand) with the weight rows of a
+// fragment taken as {16a + 4j + b}: lane (fr, fh) then owns, for activation row 16i + fr, the 16
+// CONTIGUOUS output columns 16fh + 4j + e — 64-byte vector stores, full lines per row across fh.
 #include "swc_common.h"
 
 namespace {
 
-constexpr int BM = 128;
-constexpr int BN = 128;
-constexpr int ROW_BYTES = 128;            // bytes of K per LDS row per slice
-constexpr int TILE_BYTES = BM * ROW_BYTES;  // 16 KiB per operand per stage
-constexpr int NTHREADS = 256;
+constexpr int ROW_BYTES = 128;  // bytes of K per LDS row per slice
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
-// 16 bytes per lane, global -> LDS without a VGPR round trip.  `lds_base` must be wave-uniform:
-// the hardware writes lane l at lds_base + 16 * l.
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_base) {
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)gsrc,
-        (__attribute__((address_space(3))) void*)lds_base, 16, 0, 0);
+// 16 bytes per lane, global -> LDS (global_load_lds_dwordx4).  `lds_addr` is the wave-uniform LDS byte
+// address; lane l lands at lds_addr + 16 l.  Written as inline asm on purpose: hipcc drains a
+// compiler-visible LDS-DMA (s_waitcnt vmcnt(0)) in front of the next ds_read, which would serialise the
+// prefetch of slice t+1 with the MFMAs of slice t.  Hidden in asm, the DMA is ordered by our own
+// `s_waitcnt vmcnt(N)` + barrier (cdna_hip_programming.md 5.7).  M0 is saved/restored inside the statement.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_addr)
+        : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
+// conflict-free for the four 16-lane groups of ds_read_b128, both for 16 consecutive rows (activation
+// fragments) and for the permuted weight rows {16a + 4j + b} (checked exhaustively)
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) ^ ((row >> 4) << 1)) & 7; }
-
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-    // conflict-free for the 16-lane groups of ds_read_b128, both for 16 consecutive rows (activation
-    // fragments) and for the permuted weight rows {16a + 4j + b} of the transposed-product epilogue
-    // (checked exhaustively over the four lane groups): rows r, r+2 share a 256-byte bank row.
-    return row * ROW_BYTES + ((chunk ^ swz(row)) << 4);
-}
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ swz(row)) << 4); }
 
 struct GemmP {
     const char* A;
@@ -55,22 +64,29 @@ struct GemmP {
     int n_tiles_n, n_tiles_m;
 };
 
-template <bool BF16, typename OutT>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmP p) {
-    constexpr int ES = BF16 ? 2 : 4;          // element size
-    constexpr int EPC = 16 / ES;              // elements per 16-byte chunk
-    constexpr int BK = ROW_BYTES / ES;        // elements of K per slice
+template <bool BF16, typename OutT, int MT, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p) {
+    constexpr int ES = BF16 ? 2 : 4;    // element size
+    constexpr int EPC = 16 / ES;        // elements per 16-byte chunk
+    constexpr int BK = ROW_BYTES / ES;  // elements of K per slice
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int BM = WAVES_M * MT * 16;
+    constexpr int BN = WAVES_N * 64;
+    constexpr int RPS = NT / 8;  // rows covered by one staging sweep of the workgroup
+    constexpr int NA = BM / RPS;  // A chunks per thread per slice
+    constexpr int NB = BN / RPS;  // W chunks per thread per slice
+    constexpr int A_BYTES = BM * ROW_BYTES;
+    constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [stage][A|B][TILE_BYTES]
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage][A rows | W rows][128 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
 
-    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so
-    // give each XCD a contiguous run of tiles (neighbours share the A panel in its L2).
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so give each XCD
+    // a contiguous run of tiles (neighbours share the A panel in its L2).  Bijective for any grid size.
     const int nwg = gridDim.x;
     int bid = blockIdx.x;
     {
@@ -81,122 +97,147 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmP p) {
     const int tn = bid - tm * p.n_tiles_n;
     const int bm = tm * BM, bn = tn * BN;
 
-    // ---- per-thread staging geometry: 4 A chunks + 4 W chunks per slice
-    const int ld_chunk = tid & 7;
-    int a_b[4], a_t[4];
-    bool a_rowok[4];
-    long w_rowoff[4];
-    bool w_rowok[4];
+    // ---- per-thread staging geometry
+    const int ld_pos = tid & 7;  // chunk POSITION this lane lands on
+    int a_b[NA], a_t[NA], a_chunk[NA];
+    bool a_rowok[NA];
+    long w_rowoff[NB];
+    int w_chunk[NB];
+    bool w_rowok[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 3) + 32 * i;
+    for (int i = 0; i < NA; ++i) {
+        const int row = (tid >> 3) + RPS * i;
         const int r = bm + row;
         a_rowok[i] = r < p.M;
         const int rr = a_rowok[i] ? r : 0;
         a_b[i] = rr / p.t_out;
         a_t[i] = rr - a_b[i] * p.t_out;
+        a_chunk[i] = ld_pos ^ swz(row);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int row = (tid >> 3) + RPS * i;
         const int n = bn + row;
         w_rowok[i] = n < p.N;
         w_rowoff[i] = (long)(w_rowok[i] ? n : 0) * p.ldw;
-    }
-
-    // Direct global->LDS staging (global_load_lds_dwordx4): one wave-instruction fills 8 LDS rows
-    // (1 KiB, lane-linear), so the XOR swizzle lives on the SOURCE address: the lane that lands on
-    // chunk position p of row r fetches logical chunk p ^ ((r >> 1) & 7).  Lanes whose row / tap /
-    // K-chunk is out of range fetch a 16-byte device zero page instead (no zero-fill path exists).
-    int a_chunk[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (tid >> 3) + 32 * i;
-        a_chunk[i] = ld_chunk ^ swz(row);
+        w_chunk[i] = ld_pos ^ swz(row);
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    // Lanes whose tap / K-chunk is out of range fetch a 16-byte device zero page (LDS-DMA cannot
+    // zero-fill).  Rows beyond M / N are clamped instead (their results are never stored).
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const bool plain = (p.taps == 1) && (p.K % BK == 0) && (p.stride == 1) && (p.pad == 0) && (p.t_in == p.t_out);
+    const char* a_ptr[NA];
+    const char* w_ptr[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (tid >> 3) + RPS * i;
+        int r = bm + row;
+        r = r < p.M ? r : p.M - 1;
+        a_ptr[i] = p.A + ((long)r * p.lda + a_chunk[i] * EPC) * ES;  // plain GEMM: t_in == t_out == M
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int row = (tid >> 3) + RPS * i;
+        int n = bn + row;
+        n = n < p.N ? n : p.N - 1;
+        w_ptr[i] = p.W + ((long)n * p.ldw + w_chunk[i] * EPC) * ES;
+    }
     auto stage_slice = [&](int kt, int stage) {
+        const unsigned sa = smem_base + stage * STAGE_BYTES + 8 * wave_u * ROW_BYTES;
+        const unsigned sb = sa + A_BYTES;
+        if (plain) {
+            const long koff = (long)kt * ROW_BYTES;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) glds16(a_ptr[i] + koff, sa + RPS * i * ROW_BYTES);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) glds16(w_ptr[i] + koff, sb + RPS * i * ROW_BYTES);
+            return;
+        }
         const int tap = kt / p.kc_per_tap;
         const int kc = kt - tap * p.kc_per_tap;
         const int shift = tap * p.dil - p.pad;
-        char* sa = smem + stage * 2 * TILE_BYTES;
-        char* sb = sa + TILE_BYTES;
+        const char* zero = reinterpret_cast<const char*>(g_zero16);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int k0 = kc * BK + a_chunk[i] * EPC;
-            const bool kok = k0 < p.K;
             const int ts = a_t[i] * p.stride + shift;
-            const bool ok = a_rowok[i] && kok && ts >= 0 && ts < p.t_in;
-            const char* src = reinterpret_cast<const char*>(g_zero16);
-            if (ok) src = p.A + (((long)a_b[i] * p.t_in + ts) * p.lda + k0) * ES;
-            glds16(src, sa + (32 * i + 8 * wave_u) * ROW_BYTES);
-            const char* srcw = reinterpret_cast<const char*>(g_zero16);
-            if (w_rowok[i] && kok) srcw = p.W + (w_rowoff[i] + (long)tap * p.K + k0) * ES;
-            glds16(srcw, sb + (32 * i + 8 * wave_u) * ROW_BYTES);
+            const bool ok = a_rowok[i] && k0 < p.K && ts >= 0 && ts < p.t_in;
+            const char* src = p.A + (((long)a_b[i] * p.t_in + (ok ? ts : 0)) * p.lda + (ok ? k0 : 0)) * ES;
+            glds16(ok ? src : zero, sa + RPS * i * ROW_BYTES);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int k0 = kc * BK + w_chunk[i] * EPC;
+            const bool ok = w_rowok[i] && k0 < p.K;
+            const char* src = p.W + (w_rowoff[i] + (long)tap * p.K + (ok ? k0 : 0)) * ES;
+            glds16(ok ? src : zero, sb + RPS * i * ROW_BYTES);
         }
     };
+    // the LDS-DMA is invisible to the compiler: order it ourselves
+    auto dma_fence = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
 
-    f32x4 acc[4][4];
+    f32x4 acc[MT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nkt = p.taps * p.kc_per_tap;
     stage_slice(0, 0);
-    __syncthreads();  // drains vmcnt (the LDS-DMA) before the barrier
+    dma_fence();
 
     const int fr = lane & 15, fh = lane >> 4;
+    const int a_row0 = wr * (MT * 16) + fr;
+    const int b_row0 = wc * 64 + 16 * (fr >> 2) + (fr & 3);
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) stage_slice(kt + 1, cur ^ 1);
-        const char* sa = smem + cur * 2 * TILE_BYTES;
-        const char* sb = sa + TILE_BYTES;
+        const char* sa = smem + cur * STAGE_BYTES;
+        const char* sb = sa + A_BYTES;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            uint4 fa[4], fb[4];
+            uint4 fa[MT], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ra_row = wr * 64 + i * 16 + fr;
-                fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off(ra_row, fh + 4 * g));
-                // weight rows are taken in the order {16a + 4i + b}: with the weight fragment as the
-                // MFMA's row operand, lane (fr, fh) then owns 16 CONTIGUOUS output columns 16fh + 4i + e
-                const int rb_row = wc * 64 + 16 * (fr >> 2) + 4 * i + (fr & 3);
-                fb[i] = *reinterpret_cast<const uint4*>(sb + lds_off(rb_row, fh + 4 * g));
-            }
+            for (int j = 0; j < 4; ++j)
+                fb[j] = *reinterpret_cast<const uint4*>(sb + lds_off(b_row0 + 4 * j, fh + 4 * g));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off(a_row0 + 16 * i, fh + 4 * g));
             if constexpr (BF16) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            *reinterpret_cast<bf16x8*>(&fb[j]), *reinterpret_cast<bf16x8*>(&fa[i]),
-                            acc[i][j], 0, 0, 0);
+                            *reinterpret_cast<bf16x8*>(&fb[j]), *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < MT; ++i) {
                         const float av = __uint_as_float(reinterpret_cast<const unsigned*>(&fa[i])[e]);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float bv =
-                                __uint_as_float(reinterpret_cast<const unsigned*>(&fb[j])[e]);
-                            acc[i][j] =
-                                __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
+                            const float bv = __uint_as_float(reinterpret_cast<const unsigned*>(&fb[j])[e]);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
                         }
                     }
-                }
             }
         }
-        __syncthreads();
+        dma_fence();
     }
 
-    // ---- epilogue.  Transposed product: D[n][m], so lane (fr, fh) holds, for row m = 16i + fr,
-    // the 16 contiguous columns 16fh + 4j + e (j = 0..3, e = 0..3) of its wave's 64-column slab.
+    // ---- epilogue: lane (fr, fh) holds, for row 16i + fr, columns 16fh + 4j + e of its 64-column slab
     OutT* C = reinterpret_cast<OutT*>(p.C);
     const int col0 = bn + wc * 64 + 16 * fh;
     const bool vec_ok = (col0 + 16 <= p.N) && ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
-                        ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0) &&
-                        ((reinterpret_cast<uintptr_t>(p.bias) & 15) == 0) &&
-                        ((reinterpret_cast<uintptr_t>(p.gamma) & 15) == 0);
+                        ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
     float bv[16], gv[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
@@ -205,8 +246,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmP p) {
         gv[c] = (p.gamma && col < p.N) ? p.gamma[col] : 1.f;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = bm + wr * 64 + i * 16 + fr;
+    for (int i = 0; i < MT; ++i) {
+        const int row = bm + wr * (MT * 16) + i * 16 + fr;
         if (row >= p.M) continue;
         float v[16];
 #pragma unroll
@@ -214,7 +255,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = acc[i][j][e] + bv[4 * j + e];
-                if (p.act == SWC_ACT_GELU) x = gelu_erf(x);
+                if (p.act == SWC_ACT_GELU) x = (sizeof(OutT) == 2) ? gelu_fast(x) : gelu_erf(x);
                 v[4 * j + e] = x * gv[4 * j + e];
             }
         if (vec_ok) {
@@ -255,7 +296,45 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_kernel(GemmP p) {
     }
 }
 
+template <bool BF16, typename OutT, int MT, int WM, int WN>
+int launch(GemmP p, hipStream_t s) {
+    constexpr int BM = WM * MT * 16, BN = WN * 64;
+    constexpr int LDS = 2 * (BM + BN) * ROW_BYTES;
+    p.n_tiles_n = (p.N + BN - 1) / BN;
+    p.n_tiles_m = (p.M + BM - 1) / BM;
+    const long nwg = (long)p.n_tiles_n * p.n_tiles_m;
+    if (nwg >= (1L << 30)) {
+        swc_set_error("swc_gemm: grid too large");
+        return SWC_E_ARG;
+    }
+    auto kern = gemm_kernel<BF16, OutT, MT, WM, WN>;
+    if (LDS > 64 * 1024) {
+        static bool attr_set = false;  // per instantiation; benign race (same value)
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) {
+                swc_set_error("swc_gemm: cannot enable %d bytes of LDS: %s", LDS, hipGetErrorString(e));
+                return SWC_E_LAUNCH;
+            }
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, s, p);
+    return SWC_OK;
+}
+
 }  // namespace
+
+// SWC_GEMM_TILE=128|256 overrides the geometry choice (benchmarking only).
+static int tile_override() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("SWC_GEMM_TILE");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
 
 extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     SWC_CHECK_ARG(a != nullptr, "swc_gemm: null args");
@@ -291,24 +370,24 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     p.act = a->act;
     const int bk = bf ? 64 : 32;
     p.kc_per_tap = (a->K + bk - 1) / bk;
-    p.n_tiles_n = (a->N + BN - 1) / BN;
-    p.n_tiles_m = (a->M + BM - 1) / BM;
-    const long nwg = (long)p.n_tiles_n * p.n_tiles_m;
-    SWC_CHECK_ARG(nwg < (1L << 30), "swc_gemm: grid too large");
-    const size_t lds = 4 * TILE_BYTES;
+    p.n_tiles_n = p.n_tiles_m = 0;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((unsigned)nwg), block(NTHREADS);
+    const bool out_bf = a->c_dtype == SWC_BF16;
+    // geometry: the 256x256 / 8-wave tile pays off when its grid still fills the 256 CUs
+    const long big_tiles = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
+    bool big = bf && a->N >= 256 && big_tiles >= 192;
+    if (tile_override() == 128) big = false;
+    if (tile_override() == 256) big = bf;
+    int rc;
     if (bf) {
-        if (a->c_dtype == SWC_BF16)
-            hipLaunchKernelGGL((gemm_kernel<true, bf16_t>), grid, block, lds, s, p);
+        if (big)
+            rc = out_bf ? launch<true, bf16_t, 8, 2, 4>(p, s) : launch<true, float, 8, 2, 4>(p, s);
         else
-            hipLaunchKernelGGL((gemm_kernel<true, float>), grid, block, lds, s, p);
+            rc = out_bf ? launch<true, bf16_t, 4, 2, 2>(p, s) : launch<true, float, 4, 2, 2>(p, s);
     } else {
-        if (a->c_dtype == SWC_BF16)
-            hipLaunchKernelGGL((gemm_kernel<false, bf16_t>), grid, block, lds, s, p);
-        else
-            hipLaunchKernelGGL((gemm_kernel<false, float>), grid, block, lds, s, p);
+        rc = out_bf ? launch<false, bf16_t, 4, 2, 2>(p, s) : launch<false, float, 4, 2, 2>(p, s);
     }
+    if (rc != SWC_OK) return rc;
     SWC_CHECK_LAUNCH("swc_gemm");
     return SWC_OK;
 }

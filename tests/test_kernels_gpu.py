@@ -41,6 +41,30 @@ def test_gemm_plain(M, N, K, dtype):
         pass
 
 
+def test_gemm_big_tile_bf16():
+    """large grids take the 256x256 / 8-wave geometry: ragged M, N, K tails and every epilogue input."""
+    ops = _ops()
+    M, N, K = 4100, 3000, 136
+    g = torch.Generator().manual_seed(77)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) / 8).to(torch.bfloat16)
+    bias, gamma, res = torch.randn(N, generator=g), torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = torch.nn.functional.gelu(A.double() @ W.double().T + bias.double()) * gamma.double() + res.double()
+    out = ops.gemm(A.to(DEV), W.to(DEV), M, N, K, bias=bias.to(DEV), gamma=gamma.to(DEV), residual=res.to(DEV),
+                   act=ops.ACT_GELU)
+    assert _rel(out, ref) < 3e-5
+    outb = ops.gemm(A.to(DEV), W.to(DEV), M, N, K, bias=bias.to(DEV), out_dtype=torch.bfloat16)
+    assert _rel(outb.float(), A.double() @ W.double().T + bias.double()) < 8e-3
+    # conv gather through the big tile: k=7 dilated over [B, T, C]
+    B, T, Cin, Cout = 16, 1024, 64, 512
+    x = torch.randn(B, Cin, T, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, 7, generator=g) / 20).to(torch.bfloat16)
+    refc = torch.nn.functional.conv1d(x.double(), w.double(), padding=9, dilation=3)
+    outc = ops.gemm(x.transpose(1, 2).contiguous().to(DEV), w.permute(0, 2, 1).reshape(Cout, -1).contiguous().to(DEV),
+                    B * T, Cout, Cin, lda=Cin, ldw=7 * Cin, taps=7, dil=3, pad=9, t_in=T, t_out=T)
+    assert _rel(outc.view(B, T, Cout).transpose(1, 2), refc) < 3e-5
+
+
 def test_gemm_identity_asymmetric():
     ops = _ops()
     n = 128

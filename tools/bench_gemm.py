@@ -6,10 +6,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from simwhisper_codec_amd import ops
 
-SHAPES = [  # (name, M, N, K)
-    ("qkv      ", 16000, 2304, 768), ("out_proj ", 16000, 768, 768), ("fc1      ", 16000, 3072, 768),
-    ("fc2      ", 16000, 768, 3072), ("pwconv1  ", 32000, 4096, 512), ("pwconv2  ", 32000, 512, 4096),
-    ("head     ", 32000, 642, 512), ("idft     ", 32000, 640, 648),
+SHAPES = [  # (name, M, N, K, gelu, out_bf16)
+    ("qkv      ", 16000, 2304, 768, 0, 1), ("out_proj ", 16000, 768, 768, 0, 0), ("fc1+gelu ", 16000, 3072, 768, 1, 1),
+    ("fc2      ", 16000, 768, 3072, 0, 0), ("pw1+gelu ", 32000, 4096, 512, 1, 1), ("pwconv2  ", 32000, 512, 4096, 0, 0),
+    ("head     ", 32000, 642, 512, 0, 0), ("idft     ", 32000, 640, 648, 0, 0),
 ]
 
 def main():
@@ -17,20 +17,25 @@ def main():
     dev = "cuda"
     for dt in dts:
         tot_f = tot_t = 0.0
-        for name, M, N, K in SHAPES:
+        for name, M, N, K, gelu, obf in SHAPES:
             A = (torch.randn(M, K, device=dev) * 0.5).to(dt)
             W = (torch.randn(N, K, device=dev) * 0.05).to(dt)
             bias = torch.randn(N, device=dev)
-            out = torch.empty(M, N, device=dev, dtype=dt if dt == torch.bfloat16 else torch.float32)
+            ldc = (N + 7) // 8 * 8
+            out = torch.empty(M, ldc, device=dev, dtype=torch.bfloat16 if (obf and dt == torch.bfloat16) else torch.float32)
+            res = None if obf else torch.randn(M, ldc, device=dev)
+            kw = dict(bias=bias, out=out, ldc=ldc, act=ops.ACT_GELU if gelu else ops.ACT_NONE)
+            if res is not None:
+                kw.update(residual=res, ldr=ldc)
             for _ in range(3):
-                ops.gemm(A, W, M, N, K, bias=bias, out=out)
+                ops.gemm(A, W, M, N, K, **kw)
             torch.cuda.synchronize()
             ts = []
             for _ in range(7):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(5):
-                    ops.gemm(A, W, M, N, K, bias=bias, out=out)
+                    ops.gemm(A, W, M, N, K, **kw)
                 e1.record(); torch.cuda.synchronize()
                 ts.append(e0.elapsed_time(e1) / 5)
             t = statistics.median(ts)
