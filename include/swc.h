@@ -34,6 +34,19 @@ extern "C" {
 
 #define SWC_F32 0
 #define SWC_BF16 1
+/*
+ * SWC_F16S — "split f16": an f32 matrix X[rows][K] (K % 32 == 0) stored as fp16 [rows][2K]; every block of 32
+ * logical elements k = 32q .. 32q+31 is 32 hi halves followed by 32 lo halves, hi = f16(x * 2^s),
+ * lo = f16(x * 2^s - hi): 22 significand bits per element at 4 bytes, i.e. the byte layout and strides of the
+ * f32 matrix.  swc_gemm contracts two such operands with three f16 MFMAs per k-step (hi*hi + hi*lo + lo*hi,
+ * f32 accumulate): f32-class accuracy (the dropped lo*lo term and the 2^-22 representation error are below the
+ * f32 accumulation rounding of a K >= 64 dot product) at 3/16 of the exact-f32 MFMA cycles.  `lda/ldw/ldc`
+ * stay in LOGICAL elements.  The power-of-two scales are the caller's: alpha un-does them.
+ */
+#define SWC_F16S 2
+/* scale 2^s of every split-f16 ACTIVATION written by swc_layernorm / swc_snake_aa / swc_attention_ex:
+ * |x| up to 1023 without saturation, lo halves normal down to |x| ~ 2e-3 */
+#define SWC_F16S_ACT_SCALE 64.0f
 
 #define SWC_ACT_NONE 0
 #define SWC_ACT_GELU 1 /* exact erf GELU == nn.GELU() / ACT2FN["gelu"] */
@@ -59,8 +72,10 @@ int swc_device_count(void);
  * Output row r = b*t_out + t reads, for tap j, input row
  *   b*t_in + t*stride + j*dil - pad   (zero if outside [0, t_in)).
  * A plain GEMM is taps=1, stride=1, dil=1, pad=0, t_in=t_out=M.
- * epilogue: v = acc + bias[n]; v = act(v); v *= gamma[n]; v += residual[r][n].
- * K must be a multiple of 4 (f32) / 8 (bf16); lda, ldw keep rows 16-byte aligned.
+ * epilogue: v = alpha * acc + bias[n]; v = act(v); v *= gamma[n]; v += residual[r][n];
+ *           C = (c_dtype == F16S) ? split(v * out_scale) : v.     (alpha == 0 is read as 1)
+ * K must be a multiple of 4 (f32) / 8 (bf16) / 32 (f16s); lda, ldw keep rows 16-byte aligned.
+ * a_dtype F16S: A and W are both split-f16; c_dtype F16S needs N % 32 == 0.
  */
 typedef struct swc_gemm_args {
     const void* A;
@@ -73,6 +88,8 @@ typedef struct swc_gemm_args {
     int32_t M, N, K;
     int32_t taps, dil, stride, pad, t_in, t_out;
     int32_t a_dtype, c_dtype, act;
+    float alpha;     /* multiplies the accumulator (undoes operand scales); 0 means 1 */
+    float out_scale; /* F16S output only: 2^s applied before the split; 0 means 1 */
 } swc_gemm_args;
 int swc_gemm(const swc_gemm_args* args, void* stream);
 
@@ -86,6 +103,9 @@ int swc_gemm(const swc_gemm_args* args, void* stream);
  */
 int swc_attention(const void* qkv, void* out, const int32_t* lens, int32_t B, int32_t T,
                   int32_t H, int32_t dtype, void* stream);
+/* same with f32 qkv in and the output written as out_dtype (F32 | F16S at SWC_F16S_ACT_SCALE) */
+int swc_attention_ex(const void* qkv, void* out, const int32_t* lens, int32_t B, int32_t T, int32_t H,
+                     int32_t out_dtype, void* stream);
 
 /*
  * LayerNorm over the last dim.  Replaces nn.LayerNorm calls modules.py:216,224,
@@ -178,6 +198,10 @@ int swc_istft_ola(const float* frames, const float* window_sq, float* wav, int32
 
 /* f32 -> bf16 cast (weight packing / mode switches) */
 int swc_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
+/* f32 [rows][ldx] (first K columns) -> split-f16 [rows][K] logical (K % 32 == 0), x scaled by `scale` */
+int swc_cast_f32_f16s(const float* x, int64_t ldx, void* y, int64_t rows, int32_t K, float scale,
+                      void* stream);
+
 
 #ifdef __cplusplus
 }

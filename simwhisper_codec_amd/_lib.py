@@ -13,7 +13,8 @@ import torch  # noqa: F401  (must precede CDLL: shares PyTorch's HIP runtime)
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libswc_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16S = 0, 1, 2
+F16S_ACT_SCALE = 64.0  # SWC_F16S_ACT_SCALE in include/swc.h
 ACT_NONE, ACT_GELU = 0, 1
 
 
@@ -30,6 +31,7 @@ class GemmArgs(C.Structure):
         ("taps", C.c_int32), ("dil", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("t_in", C.c_int32), ("t_out", C.c_int32),
         ("a_dtype", C.c_int32), ("c_dtype", C.c_int32), ("act", C.c_int32),
+        ("alpha", C.c_float), ("out_scale", C.c_float),
     ]
 
 
@@ -39,6 +41,7 @@ _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
     "swc_gemm": [C.POINTER(GemmArgs), _P],
     "swc_attention": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "swc_attention_ex": [_P, _P, _P, _I, _I, _I, _I, _P],
     "swc_layernorm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "swc_dwconv7_ln": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
     "swc_snake_aa": [_P, _P, _P, _P, C.POINTER(_F), _I, _I, _I, _I, _P],
@@ -52,6 +55,7 @@ SIGNATURES = {
     "swc_istft_spec": [_P, _L, _P, _L, _L, _I, _P],
     "swc_istft_ola": [_P, _P, _P, _I, _I, _P],
     "swc_cast_f32_bf16": [_P, _P, _L, _P],
+    "swc_cast_f32_f16s": [_P, _L, _P, _L, _I, _F, _P],
 }
 PLAIN = {"swc_version": ([], C.c_int), "swc_last_error": ([], C.c_char_p), "swc_device_count": ([], C.c_int)}
 

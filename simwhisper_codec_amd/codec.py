@@ -19,6 +19,7 @@ Ragged `decode` batches are padded to the batch maximum exactly like the referen
 because its un-masked up-sampler / Vocos make short utterances depend on that maximum.
 """
 import logging
+import math
 import os
 
 import torch
@@ -28,7 +29,12 @@ import yaml
 from . import ops, spec
 from ._lib import SwcError
 
-PRECISIONS = ("fp32", "mixed", "bf16")
+# precision presets: (encode-side GEMM operands, decode-side GEMM operands)
+#   f32  : exact-f32 MFMA (v_mfma_f32_16x16x4_f32)
+#   f16s : split-f16, 3 f16 MFMAs per k-step, f32-class accuracy (SWC_F16S in include/swc.h)
+#   bf16 : bf16 MFMA, f32 accumulate
+PRECISIONS = {"fp32": ("f32", "f32"), "mixed": ("f16s", "bf16"), "mixed_f32": ("f32", "bf16"), "bf16": ("bf16", "bf16")}
+_TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16s": torch.float16}
 
 
 class _Node(nn.Module):
@@ -51,6 +57,19 @@ class _Layer:
 
 class _Packed:
     """Device-resident, GEMM-ready weights for one compute dtype per stage."""
+
+
+class _PW:
+    """One packed GEMM weight: tensor in the stage's operand format + the accumulator scale that
+    undoes the power-of-two operand scales (1 except for split-f16)."""
+    __slots__ = ("w", "alpha")
+
+    def __init__(self, w, alpha=1.0):
+        self.w, self.alpha = w, alpha
+
+    @property
+    def shape(self):
+        return self.w.shape
 
 
 def _fold_wn(sd, p):
@@ -136,9 +155,8 @@ class AudioCodec(nn.Module):
 
     # ------------------------------------------------------------- packing
     def _dtypes(self):
-        enc = torch.float32 if self._precision in ("fp32", "mixed") else torch.bfloat16
-        dec = torch.float32 if self._precision == "fp32" else torch.bfloat16
-        return enc, dec
+        e, d = PRECISIONS[self._precision]
+        return _TORCH_DT[e], _TORCH_DT[d]
 
     def _packed(self):
         dev = self._buffers_device()
@@ -160,8 +178,16 @@ class AudioCodec(nn.Module):
         P.edt, P.ddt = edt, ddt
 
         def W(t, dt):
+            """[N, taps*K] f32 -> packed operand.  split-f16 weights are scaled by the power of two that puts
+            max|w| in [8192, 16384): lo halves stay normal fp16 numbers, nothing overflows."""
             t = t.to(dev, torch.float32).contiguous()
-            return ops.cast_bf16(t) if dt == torch.bfloat16 else t
+            if dt == torch.bfloat16:
+                return _PW(ops.cast_bf16(t))
+            if dt == torch.float16:
+                mx = float(t.abs().max())
+                sw = 2.0 ** math.floor(math.log2(16384.0 / mx)) if mx > 0 else 1.0
+                return _PW(ops.cast_f16s(t.view(t.shape[0], -1), t.shape[-1], scale=sw), 1.0 / (ops.F16S_ACT_SCALE * sw))
+            return _PW(t)
 
         def V(t):
             return t.to(dev, torch.float32).contiguous()
@@ -207,10 +233,13 @@ class AudioCodec(nn.Module):
         # ---- encode side
         e = gp["acoustic_encoder"]
         P.D, P.He, P.n_mel = e["d_model"], e["encoder_attention_heads"], e["num_mel_bins"]
-        P.dft = V(spec.dft_basis_400())                                    # [402][400] f32 always
+        P.dft = _PW(V(spec.dft_basis_400()))                               # [402][400] f32 always
         fb = torch.from_numpy(spec.slaney_mel_filters(n_mels=P.n_mel)).float().T.contiguous()  # [80][201]
-        P.melw = V(torch.nn.functional.pad(fb, (0, 208 - 201)))           # [80][208]
-        P.c1w, P.c1b = W(conv_w(sd["acoustic_encoder.conv1.weight"]), edt), V(sd["acoustic_encoder.conv1.bias"])
+        P.melw = _PW(V(torch.nn.functional.pad(fb, (0, 208 - 201))))      # [80][208]
+        # conv1 contracts K = 80 mel bins per tap: not a multiple of 32, so split-f16 keeps it on the exact-f32 path
+        c1dt = torch.float32 if edt == torch.float16 else edt
+        P.c1dt = c1dt
+        P.c1w, P.c1b = W(conv_w(sd["acoustic_encoder.conv1.weight"]), c1dt), V(sd["acoustic_encoder.conv1.bias"])
         P.c2w, P.c2b = W(conv_w(sd["acoustic_encoder.conv2.weight"]), edt), V(sd["acoustic_encoder.conv2.bias"])
         P.enc_layers = layers("acoustic_encoder", e["encoder_layers"], edt)
         P.enc_ln = (V(sd["acoustic_encoder.layer_norm.weight"]), V(sd["acoustic_encoder.layer_norm.bias"]))
@@ -265,22 +294,36 @@ class AudioCodec(nn.Module):
         return P
 
     # --------------------------------------------------------- sub-graphs
-    def _cast(self, x, dt):
-        return ops.cast_bf16(x) if (dt == torch.bfloat16 and x.dtype != dt) else x
+    def _cast(self, x, dt, K=None):
+        """f32 -> the stage's GEMM operand format (no-op for f32)."""
+        if dt == torch.bfloat16 and x.dtype != dt:
+            return ops.cast_bf16(x)
+        if dt == torch.float16 and x.dtype != dt:
+            return ops.cast_f16s(x, x.shape[-1] if K is None else K)
+        return x
+
+    @staticmethod
+    def _mm(A, pw, M, N, K, out_dtype=None, **kw):
+        """swc_gemm against a packed weight; split-f16 outputs are written at the activation scale."""
+        if out_dtype == torch.float16:
+            kw["out_scale"] = ops.F16S_ACT_SCALE
+        return ops.gemm(A, pw.w, M, N, K, alpha=pw.alpha, out_dtype=out_dtype, **kw)
 
     def _transformer(self, h, lens, B, T, layers, H, dt):
         """12 x OmniWhisperTransformerLayer (modules.py:214-232). h: [B*T, D] f32 residual stream (updated in place)."""
         D = h.shape[-1]
         M = B * T
+        # q/k/v feed the attention kernel, which reads f32 or bf16 (split-f16 is a GEMM-operand format only)
+        qdt = torch.float32 if dt == torch.float16 else dt
         for L in layers:
             x = ops.layernorm(h, L.ln1[0], L.ln1[1], 1e-5, B=B, t_in=T, C_=D, out_dtype=dt)
-            qkv = ops.gemm(x, L.wqkv, M, 3 * D, D, lda=D, bias=L.bqkv, out_dtype=dt)
-            a = ops.attention(qkv, lens, B, T, H)
-            ops.gemm(a, L.wo, M, D, D, lda=D, bias=L.bo, residual=h, out=h)
+            qkv = self._mm(x, L.wqkv, M, 3 * D, D, lda=D, bias=L.bqkv, out_dtype=qdt)
+            a = ops.attention(qkv, lens, B, T, H, out_dtype=dt)
+            self._mm(a, L.wo, M, D, D, lda=D, bias=L.bo, residual=h, out=h)
             x = ops.layernorm(h, L.ln2[0], L.ln2[1], 1e-5, B=B, t_in=T, C_=D, out_dtype=dt)
-            F_ = L.w1.shape[0]
-            f = ops.gemm(x, L.w1, M, F_, D, lda=D, bias=L.b1, act=ops.ACT_GELU, out_dtype=dt)
-            ops.gemm(f, L.w2, M, D, F_, lda=F_, bias=L.b2, residual=h, out=h)
+            F_ = L.b1.shape[0]
+            f = self._mm(x, L.w1, M, F_, D, lda=D, bias=L.b1, act=ops.ACT_GELU, out_dtype=dt)
+            self._mm(f, L.w2, M, D, F_, lda=F_, bias=L.b2, residual=h, out=h)
         return h
 
     def _res_units(self, h, units, B, T, C, dt):
@@ -288,25 +331,25 @@ class AudioCodec(nn.Module):
         M = B * T
         for u in units:
             y = ops.snake_aa(h, u["a0"], u["b0"], u["f0"], B=B, T=T, C_=C, out_dtype=dt)
-            y = ops.gemm(y, u["w1"], M, C, C, lda=C, ldw=7 * C, bias=u["c1"], taps=7, dil=u["dil"], pad=3 * u["dil"],
+            y = self._mm(y, u["w1"], M, C, C, lda=C, ldw=7 * C, bias=u["c1"], taps=7, dil=u["dil"], pad=3 * u["dil"],
                          t_in=T, t_out=T)
             y = ops.snake_aa(y, u["a2"], u["b2"], u["f2"], B=B, T=T, C_=C, out_dtype=dt)
-            ops.gemm(y, u["w3"], M, C, C, lda=C, bias=u["c3"], residual=h, out=h)
+            self._mm(y, u["w3"], M, C, C, lda=C, bias=u["c3"], residual=h, out=h)
         return h
 
     def _logmel(self, wav, n_dev, n_host, P):
         """Whisper log-mel of the valid frames (+2 halo) on the zero-extended, reflect-padded signal
-        (feature_extractor.py:86-112). wav: [B, >=max n] f32. Returns mel [B, Tm, 80] (encode dtype), Tm."""
+        (feature_extractor.py:86-112). wav: [B, >=max n] f32. Returns mel [B, Tm, 80] (conv1 operand dtype), Tm."""
         B = wav.shape[0]
         Tm = min(spec.MEL_FRAMES, max(spec.mel_len(n) for n in n_host) + 2)
         fr = ops.mel_frames(wav, n_dev, spec.CHUNK_SAMPLES, B=B, T=Tm)
         M = B * Tm
-        dft = ops.gemm(fr, P.dft, M, 402, 400, lda=400)
+        dft = self._mm(fr, P.dft, M, 402, 400, lda=400)
         pw = ops.mel_power(dft, 402, M, 208)
-        mp = ops.gemm(pw, P.melw, M, P.n_mel, 208, lda=208)
+        mp = self._mm(pw, P.melw, M, P.n_mel, 208, lda=208)
         umax = torch.full((B,), -10.0 if Tm < spec.MEL_FRAMES else float("-inf"), device=wav.device, dtype=torch.float32)
         ops.mel_logmax(mp, P.n_mel, umax, B=B, T=Tm, n_mel=P.n_mel)
-        mel = ops.mel_final(mp, P.n_mel, umax, B=B, T=Tm, n_mel=P.n_mel, ldo=P.n_mel, out_dtype=P.edt)
+        mel = ops.mel_final(mp, P.n_mel, umax, B=B, T=Tm, n_mel=P.n_mel, ldo=P.n_mel, out_dtype=P.c1dt)
         return mel, Tm
 
     def _encode_mel(self, mel, Tm, t_full, tok_host, P):
@@ -316,55 +359,56 @@ class AudioCodec(nn.Module):
         B, dt, D = mel.shape[0], P.edt, P.D
         dev = mel.device
         Ttok = max(1, min(t_full, max(tok_host)))
-        c1 = ops.gemm(mel, P.c1w, B * Tm, D, P.n_mel, lda=P.n_mel, ldw=3 * P.n_mel, bias=P.c1b, taps=3, pad=1, t_in=Tm,
+        c1 = self._mm(mel, P.c1w, B * Tm, D, P.n_mel, lda=P.n_mel, ldw=3 * P.n_mel, bias=P.c1b, taps=3, pad=1, t_in=Tm,
                       t_out=Tm, out_dtype=dt)
-        h = ops.gemm(c1, P.c2w, B * Ttok, D, D, lda=D, ldw=3 * D, bias=P.c2b, taps=3, stride=2, pad=1, t_in=Tm, t_out=Ttok)
+        h = self._mm(c1, P.c2w, B * Ttok, D, D, lda=D, ldw=3 * D, bias=P.c2b, taps=3, stride=2, pad=1, t_in=Tm, t_out=Ttok)
         lens = torch.tensor(tok_host, dtype=torch.int32, device=dev)
         self._transformer(h, lens, B, Ttok, P.enc_layers, P.He, dt)
         s = P.stack
         tds_full = spec.cdiv(t_full, s)
         Tds = min(tds_full, spec.cdiv(Ttok, s) + 64)
-        hn = torch.zeros((B, Tds * s, D), device=dev, dtype=dt)  # encoder output is exactly zero beyond each length
+        # encoder output is exactly zero beyond each length (zero halves are a zero in split-f16 too)
+        hn = torch.zeros((B, Tds * s, ops._w(dt, D)), device=dev, dtype=dt)
         ops.layernorm(h, P.enc_ln[0], P.enc_ln[1], 1e-5, B=B, t_in=Ttok, t_out=Tds * s, C_=D, lens=lens, out=hn)
-        hd = ops.gemm(hn, P.inw, B * Tds, P.hid, s * D, lda=s * D, bias=P.inb)
+        hd = self._mm(hn, P.inw, B * Tds, P.hid, s * D, lda=s * D, bias=P.inb)
         self._res_units(hd, P.down_units, B, Tds, P.hid, dt)
-        z = ops.gemm(self._cast(hd, dt), P.tlw, B * Tds, P.lat, P.hid, lda=P.hid, bias=P.tlb)
+        z = self._mm(self._cast(hd, dt), P.tlw, B * Tds, P.lat, P.hid, lda=P.hid, bias=P.tlb)
         return z.view(B, Tds, P.lat), Tds, [spec.cdiv(t, s) for t in tok_host]
 
     def _decode_latent(self, zq, lat_host, B, T, P):
         """up-sampler + decoder + Vocos on zq [B, T, lat] f32 (already masked). Returns wav [B, T*1280] f32."""
         dt, dev = P.ddt, zq.device
         s, D = P.stack, P.Dd
-        h = ops.gemm(self._cast(zq, dt), P.flw, B * T, P.uhid, P.lat, lda=P.lat, bias=P.flb)
+        h = self._mm(self._cast(zq, dt), P.flw, B * T, P.uhid, P.lat, lda=P.lat, bias=P.flb)
         self._res_units(h, P.up_units, B, T, P.uhid, dt)
         # to_stacked with re-ordered rows: [B*T, s*D] is the un-stacked [B, s*T, D] token stream
-        x = ops.gemm(self._cast(h, dt), P.tsw, B * T, s * D, P.uhid, lda=P.uhid, bias=P.tsb)
+        x = self._mm(self._cast(h, dt), P.tsw, B * T, s * D, P.uhid, lda=P.uhid, bias=P.tsb)
         Tt = s * T
         x = x.view(B * Tt, D)
         lens = torch.tensor([l * s for l in lat_host], dtype=torch.int32, device=dev)
         self._transformer(x, lens, B, Tt, P.dec_layers, P.Hd, dt)
         hn = ops.layernorm(x, P.dec_ln[0], P.dec_ln[1], 1e-5, B=B, t_in=Tt, C_=D, lens=lens, out_dtype=dt)
-        y3 = ops.gemm(hn, P.d1w, B * Tt, 3 * D, D, lda=D)
+        y3 = self._mm(hn, P.d1w, B * Tt, 3 * D, D, lda=D)
         Tv = 2 * Tt
         d1 = ops.deconv_col2im(y3, P.d1b, B=B, T=Tt, C_=D, s=2, t_out=Tv + 1, out_dtype=dt)
-        mel = ops.gemm(d1, P.d2w, B * Tv, P.vin, D, lda=D, ldw=3 * D, bias=P.d2b, taps=3, pad=2, t_in=Tv + 1, t_out=Tv,
+        mel = self._mm(d1, P.d2w, B * Tv, P.vin, D, lda=D, ldw=3 * D, bias=P.d2b, taps=3, pad=2, t_in=Tv + 1, t_out=Tv,
                        out_dtype=dt)
         return self._vocos(mel, B, Tv, P)
 
     def _vocos(self, mel, B, Tv, P):
         """Vocos backbone + ISTFT head (modules.py:1492-1504, 1229-1248, 1053-1082, 831-886). mel [B, Tv, 80]."""
         dt, C, M = P.ddt, P.vdim, B * Tv
-        x = ops.gemm(mel, P.emw, M, C, P.vin, lda=P.vin, ldw=7 * P.vin, bias=P.emb, taps=7, pad=3, t_in=Tv, t_out=Tv)
+        x = self._mm(mel, P.emw, M, C, P.vin, lda=P.vin, ldw=7 * P.vin, bias=P.emb, taps=7, pad=3, t_in=Tv, t_out=Tv)
         x = ops.layernorm(x, P.vnorm[0], P.vnorm[1], 1e-6, B=B, t_in=Tv, C_=C)
         for blk in P.blocks:
             y = ops.dwconv7_ln(x, blk["dw"], blk["db"], blk["ln"][0], blk["ln"][1], 1e-6, B=B, T=Tv, C_=C, out_dtype=dt)
-            y = ops.gemm(y, blk["w1"], M, P.vint, C, lda=C, bias=blk["b1"], act=ops.ACT_GELU, out_dtype=dt)
-            ops.gemm(y, blk["w2"], M, C, P.vint, lda=P.vint, bias=blk["b2"], gamma=blk["g"], residual=x, out=x)
+            y = self._mm(y, blk["w1"], M, P.vint, C, lda=C, bias=blk["b1"], act=ops.ACT_GELU, out_dtype=dt)
+            self._mm(y, blk["w2"], M, C, P.vint, lda=P.vint, bias=blk["b2"], gamma=blk["g"], residual=x, out=x)
         hn = ops.layernorm(x, P.vfin[0], P.vfin[1], 1e-6, B=B, t_in=Tv, C_=C, out_dtype=dt)
         ho = torch.empty((M, 648), device=mel.device, dtype=torch.float32)  # ld 648: 16-byte rows for vector stores
-        ops.gemm(hn, P.hw, M, 642, C, lda=C, bias=P.hb, out=ho, ldc=648)
+        self._mm(hn, P.hw, M, 642, C, lda=C, bias=P.hb, out=ho, ldc=648)
         sp = ops.istft_spec(ho, 648, M, 648, out_dtype=dt)
-        fr = ops.gemm(sp, P.idft, M, 640, 648, lda=648)
+        fr = self._mm(sp, P.idft, M, 640, 648, lda=648)
         return ops.istft_ola(fr, P.wsq, B=B, T=Tv)
 
     # ------------------------------------------------- reference entry points
@@ -476,7 +520,7 @@ class AudioCodec(nn.Module):
         B, _, T = mel_in.shape
         ml_host = [int(v) for v in ml.tolist()]
         mel = mel_in.to(torch.float32).transpose(1, 2).contiguous()
-        mel = self._cast(mel, P.edt)
+        mel = self._cast(mel, P.c1dt)
         t_full = (T - 1) // 2 + 1  # Conv1d(k3, s2, p1) output length
         tok = [m // 2 for m in ml_host]
         # the trimmed stem needs frames up to 2*max(tok): the given T is the true right boundary

@@ -11,7 +11,7 @@ void swc_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int swc_version(void) { return 100; }
+extern "C" int swc_version(void) { return 101; }
 
 extern "C" const char* swc_last_error(void) { return g_err; }
 

@@ -31,7 +31,7 @@ __device__ __forceinline__ float4 load4(const void* base, long idx) {
     }
 }
 
-template <bool BF16>
+template <bool BF16, bool OUT_F16S = false>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ qkv,
                                                       void* __restrict__ out,
                                                       const int* __restrict__ lens, int T, int H) {
@@ -49,12 +49,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ q
     const int q = q0 + wave * 16 + fr;  // this lane's query column
     const bool q_in = q < T;
     const long orow = ((long)b * T + (q_in ? q : T - 1)) * D + head * HD;
+    // split-f16 output rows are addressed in halves (2 per logical column)
+    unsigned short* orow_s = reinterpret_cast<unsigned short*>(out) + ((long)b * T + (q_in ? q : T - 1)) * 2L * D;
 
     if (q0 >= len) {  // whole block is padding: defined, finite output
         if (q_in) {
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                if constexpr (BF16) {
+                if constexpr (OUT_F16S) {
+                    f16s_store4(orow_s, head * HD + dt * 16 + fh * 4, 0.f, 0.f, 0.f, 0.f);
+                } else if constexpr (BF16) {
                     *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + orow + dt * 16 + fh * 4) =
                         make_uint2(0, 0);
                 } else {
@@ -168,7 +172,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ q
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const f32x4 v = o[dt] * inv;
-            if constexpr (BF16) {
+            if constexpr (OUT_F16S) {
+                f16s_store4(orow_s, head * HD + dt * 16 + fh * 4, v[0] * SWC_F16S_ACT_SCALE, v[1] * SWC_F16S_ACT_SCALE,
+                            v[2] * SWC_F16S_ACT_SCALE, v[3] * SWC_F16S_ACT_SCALE);
+            } else if constexpr (BF16) {
                 uint2 u;
                 u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
                 u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
@@ -198,5 +205,19 @@ extern "C" int swc_attention(const void* qkv, void* out, const int32_t* lens, in
     else
         hipLaunchKernelGGL(attn_kernel<false>, grid, block, 0, s, qkv, out, lens, T, H);
     SWC_CHECK_LAUNCH("swc_attention");
+    return SWC_OK;
+}
+
+extern "C" int swc_attention_ex(const void* qkv, void* out, const int32_t* lens, int32_t B, int32_t T, int32_t H,
+                                int32_t out_dtype, void* stream) {
+    if (out_dtype == SWC_F32) return swc_attention(qkv, out, lens, B, T, H, SWC_F32, stream);
+    SWC_CHECK_ARG(out_dtype == SWC_F16S, "swc_attention_ex: out_dtype must be F32 or F16S");
+    SWC_CHECK_ARG(qkv && out && lens, "swc_attention_ex: null pointer");
+    SWC_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && B <= 65535 && H <= 65535, "swc_attention_ex: bad B/T/H");
+    SWC_CHECK_ARG(aligned16(qkv) && aligned16(out), "swc_attention_ex: unaligned");
+    if (B == 0 || T == 0) return SWC_OK;
+    dim3 grid((T + QB - 1) / QB, H, B), block(256);
+    hipLaunchKernelGGL((attn_kernel<false, true>), grid, block, 0, (hipStream_t)stream, qkv, out, lens, T, H);
+    SWC_CHECK_LAUNCH("swc_attention_ex");
     return SWC_OK;
 }

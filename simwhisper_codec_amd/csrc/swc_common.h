@@ -10,6 +10,8 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short bf16_t;  // raw bf16 storage
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+struct f16s_t { unsigned short h; };  // tag type: split-f16 storage (see SWC_F16S in swc.h), addressed in halves
 
 void swc_set_error(const char* fmt, ...);
 
@@ -37,6 +39,25 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float x) {
 }
 __device__ __forceinline__ float bf16_to_f32(bf16_t x) {
     return __uint_as_float(((unsigned)x) << 16);
+}
+
+// split one scaled f32 into (hi, lo) halves; saturates instead of overflowing to inf
+__device__ __forceinline__ void f16s_split(float v, unsigned short& hi, unsigned short& lo) {
+    v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    hi = *reinterpret_cast<const unsigned short*>(&h);
+    lo = *reinterpret_cast<const unsigned short*>(&l);
+}
+// half index of logical column k inside a split row (block of 32: 32 hi then 32 lo)
+__device__ __forceinline__ long f16s_col(long k) { return (k >> 5) * 64 + (k & 31); }
+// store 4 consecutive logical columns k..k+3 (k % 4 == 0) of a split row starting at `row` (halves)
+__device__ __forceinline__ void f16s_store4(unsigned short* row, long k, float a, float b, float c, float d) {
+    unsigned short h[4], l[4];
+    f16s_split(a, h[0], l[0]); f16s_split(b, h[1], l[1]); f16s_split(c, h[2], l[2]); f16s_split(d, h[3], l[3]);
+    unsigned short* p = row + f16s_col(k);
+    *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+    *reinterpret_cast<uint2*>(p + 32) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
 }
 
 template <typename T>

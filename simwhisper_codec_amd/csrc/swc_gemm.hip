@@ -60,15 +60,18 @@ struct GemmP {
     int M, N, K;
     int taps, dil, stride, pad, t_in, t_out;
     int act;
+    float alpha, out_scale;
     int kc_per_tap;  // ceil(K / BK)
     int n_tiles_n, n_tiles_m;
 };
 
-template <bool BF16, typename OutT, int MT, int WAVES_M, int WAVES_N>
+template <int MODE, typename OutT, int MT, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p) {
-    constexpr int ES = BF16 ? 2 : 4;    // element size
-    constexpr int EPC = 16 / ES;        // elements per 16-byte chunk
-    constexpr int BK = ROW_BYTES / ES;  // elements of K per slice
+    constexpr bool BF16 = MODE == SWC_BF16;
+    constexpr bool F16S = MODE == SWC_F16S;
+    constexpr int ES = BF16 ? 2 : 4;    // bytes per LOGICAL element (split-f16 is 2 halves = 4 bytes)
+    constexpr int EPC = 16 / ES;        // logical elements per 16-byte chunk (K-tail predicate only)
+    constexpr int BK = ROW_BYTES / ES;  // logical elements of K per slice
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int BM = WAVES_M * MT * 16;
     constexpr int BN = WAVES_N * 64;
@@ -199,6 +202,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         if (kt + 1 < nkt) stage_slice(kt + 1, cur ^ 1);
         const char* sa = smem + cur * STAGE_BYTES;
         const char* sb = sa + A_BYTES;
+        uint4 ha[F16S ? MT : 1], hb[F16S ? 4 : 1];
+        (void)ha; (void)hb;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             uint4 fa[MT], fb[4];
@@ -208,7 +213,30 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
 #pragma unroll
             for (int i = 0; i < MT; ++i)
                 fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off(a_row0 + 16 * i, fh + 4 * g));
-            if constexpr (BF16) {
+            if constexpr (F16S) {
+                // chunk g = 0 holds the hi halves of this 32-element slice, g = 1 the lo halves: keep the hi
+                // fragments and fold the three products in once both are in registers (below)
+                if (g == 0) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) ha[i] = fa[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hb[j] = fb[j];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4 c = acc[i][j];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&fb[j]),
+                                                                       *reinterpret_cast<f16x8*>(&ha[i]), c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&hb[j]),
+                                                                       *reinterpret_cast<f16x8*>(&fa[i]), c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&hb[j]),
+                                                                       *reinterpret_cast<f16x8*>(&ha[i]), c, 0, 0, 0);
+                            acc[i][j] = c;
+                        }
+                }
+            } else if constexpr (BF16) {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -254,11 +282,38 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float x = acc[i][j][e] + bv[4 * j + e];
-                if (p.act == SWC_ACT_GELU) x = (sizeof(OutT) == 2) ? gelu_fast(x) : gelu_erf(x);
+                float x = acc[i][j][e] * p.alpha + bv[4 * j + e];
+                if (p.act == SWC_ACT_GELU) x = __is_same(OutT, bf16_t) ? gelu_fast(x) : gelu_erf(x);
                 v[4 * j + e] = x * gv[4 * j + e];
             }
-        if (vec_ok) {
+        if constexpr (sizeof(OutT) == sizeof(f16s_t) && !__is_same(OutT, bf16_t)) {
+            // split-f16 output: the lane's 16 columns sit inside one 32-block (col0 % 16 == 0, N % 32 == 0)
+            if (col0 + 16 <= p.N) {
+                if (p.residual) {
+                    const float4* rp = reinterpret_cast<const float4*>(p.residual + (long)row * p.ldr + col0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 r4 = rp[j];
+                        v[4 * j] += r4.x; v[4 * j + 1] += r4.y; v[4 * j + 2] += r4.z; v[4 * j + 3] += r4.w;
+                    }
+                }
+                unsigned short* rowp = reinterpret_cast<unsigned short*>(p.C) + (long)row * p.ldc * 2;
+                unsigned short h[16], l[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) f16s_split(v[c] * p.out_scale, h[c], l[c]);
+                unsigned short* hp = rowp + f16s_col(col0);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    uint4 uh, ul;
+                    uh.x = h[8 * q + 0] | ((unsigned)h[8 * q + 1] << 16); uh.y = h[8 * q + 2] | ((unsigned)h[8 * q + 3] << 16);
+                    uh.z = h[8 * q + 4] | ((unsigned)h[8 * q + 5] << 16); uh.w = h[8 * q + 6] | ((unsigned)h[8 * q + 7] << 16);
+                    ul.x = l[8 * q + 0] | ((unsigned)l[8 * q + 1] << 16); ul.y = l[8 * q + 2] | ((unsigned)l[8 * q + 3] << 16);
+                    ul.z = l[8 * q + 4] | ((unsigned)l[8 * q + 5] << 16); ul.w = l[8 * q + 6] | ((unsigned)l[8 * q + 7] << 16);
+                    reinterpret_cast<uint4*>(hp)[q] = uh;
+                    reinterpret_cast<uint4*>(hp + 32)[q] = ul;
+                }
+            }
+        } else if (vec_ok) {
             if (p.residual) {
                 const float4* rp = reinterpret_cast<const float4*>(p.residual + (long)row * p.ldr + col0);
 #pragma unroll
@@ -290,13 +345,13 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
                 if (col >= p.N) continue;
                 float x = v[c];
                 if (p.residual) x += p.residual[(long)row * p.ldr + col];
-                store_out<OutT>(C + (long)row * p.ldc + col, x);
+                if constexpr (!__is_same(OutT, f16s_t)) store_out<OutT>(C + (long)row * p.ldc + col, x);
             }
         }
     }
 }
 
-template <bool BF16, typename OutT, int MT, int WM, int WN>
+template <int MODE, typename OutT, int MT, int WM, int WN>
 int launch(GemmP p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * 64;
     constexpr int LDS = 2 * (BM + BN) * ROW_BYTES;
@@ -307,7 +362,7 @@ int launch(GemmP p, hipStream_t s) {
         swc_set_error("swc_gemm: grid too large");
         return SWC_E_ARG;
     }
-    auto kern = gemm_kernel<BF16, OutT, MT, WM, WN>;
+    auto kern = gemm_kernel<MODE, OutT, MT, WM, WN>;
     if (LDS > 64 * 1024) {
         static bool attr_set = false;  // per instantiation; benign race (same value)
         if (!attr_set) {
@@ -340,11 +395,14 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     SWC_CHECK_ARG(a != nullptr, "swc_gemm: null args");
     SWC_CHECK_ARG(a->A && a->W && a->C, "swc_gemm: null operand");
     SWC_CHECK_ARG(a->M >= 0 && a->N > 0 && a->K > 0, "swc_gemm: bad M/N/K %d %d %d", a->M, a->N, a->K);
-    SWC_CHECK_ARG(a->a_dtype == SWC_F32 || a->a_dtype == SWC_BF16, "swc_gemm: bad a_dtype");
-    SWC_CHECK_ARG(a->c_dtype == SWC_F32 || a->c_dtype == SWC_BF16, "swc_gemm: bad c_dtype");
+    SWC_CHECK_ARG(a->a_dtype == SWC_F32 || a->a_dtype == SWC_BF16 || a->a_dtype == SWC_F16S, "swc_gemm: bad a_dtype");
+    SWC_CHECK_ARG(a->c_dtype == SWC_F32 || a->c_dtype == SWC_BF16 || a->c_dtype == SWC_F16S, "swc_gemm: bad c_dtype");
+    SWC_CHECK_ARG(a->c_dtype != SWC_F16S || (a->N % 32 == 0 && a->ldc % 32 == 0 && aligned16(a->C)),
+                  "swc_gemm: split-f16 output needs N, ldc multiples of 32 (N=%d)", a->N);
     SWC_CHECK_ARG(a->act == SWC_ACT_NONE || a->act == SWC_ACT_GELU, "swc_gemm: bad act");
     const bool bf = a->a_dtype == SWC_BF16;
-    const int epc = bf ? 8 : 4;
+    const bool fs = a->a_dtype == SWC_F16S;
+    const int epc = bf ? 8 : (fs ? 32 : 4);
     SWC_CHECK_ARG(a->K % epc == 0, "swc_gemm: K=%d not a multiple of %d", a->K, epc);
     SWC_CHECK_ARG(a->lda % epc == 0 && a->ldw % epc == 0, "swc_gemm: lda/ldw break 16-byte rows");
     SWC_CHECK_ARG(aligned16(a->A) && aligned16(a->W), "swc_gemm: A/W not 16-byte aligned");
@@ -368,25 +426,30 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     p.taps = a->taps; p.dil = a->dil; p.stride = a->stride; p.pad = a->pad;
     p.t_in = a->t_in; p.t_out = a->t_out;
     p.act = a->act;
+    p.alpha = a->alpha == 0.0f ? 1.0f : a->alpha;
+    p.out_scale = a->out_scale == 0.0f ? 1.0f : a->out_scale;
     const int bk = bf ? 64 : 32;
     p.kc_per_tap = (a->K + bk - 1) / bk;
     p.n_tiles_n = p.n_tiles_m = 0;
     hipStream_t s = (hipStream_t)stream;
-    const bool out_bf = a->c_dtype == SWC_BF16;
     // geometry: the 256x256 / 8-wave tile pays off when its grid still fills the 256 CUs
     const long big_tiles = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
     bool big = bf && a->N >= 256 && big_tiles >= 192;
     if (tile_override() == 128) big = false;
     if (tile_override() == 256) big = bf;
     int rc;
+    const int cd = a->c_dtype;
+#define SWC_LAUNCH(MODE, MT, WM, WN)                                                        \
+    (cd == SWC_BF16 ? launch<MODE, bf16_t, MT, WM, WN>(p, s)                                 \
+                    : (cd == SWC_F16S ? launch<MODE, f16s_t, MT, WM, WN>(p, s) : launch<MODE, float, MT, WM, WN>(p, s)))
     if (bf) {
-        if (big)
-            rc = out_bf ? launch<true, bf16_t, 8, 2, 4>(p, s) : launch<true, float, 8, 2, 4>(p, s);
-        else
-            rc = out_bf ? launch<true, bf16_t, 4, 2, 2>(p, s) : launch<true, float, 4, 2, 2>(p, s);
+        rc = big ? SWC_LAUNCH(SWC_BF16, 8, 2, 4) : SWC_LAUNCH(SWC_BF16, 4, 2, 2);
+    } else if (fs) {
+        rc = SWC_LAUNCH(SWC_F16S, 4, 2, 2);
     } else {
-        rc = out_bf ? launch<false, bf16_t, 4, 2, 2>(p, s) : launch<false, float, 4, 2, 2>(p, s);
+        rc = SWC_LAUNCH(SWC_F32, 4, 2, 2);
     }
+#undef SWC_LAUNCH
     if (rc != SWC_OK) return rc;
     SWC_CHECK_LAUNCH("swc_gemm");
     return SWC_OK;

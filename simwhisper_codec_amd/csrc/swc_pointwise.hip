@@ -26,6 +26,20 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, floa
     *reinterpret_cast<uint2*>(p) = u;
 }
 
+// store 4 consecutive columns col..col+3 of a row; `row` points at the row start in OutT units
+// (split-f16 rows are addressed in halves: 2 per logical column)
+template <typename OutT>
+__device__ __forceinline__ void store_row4(OutT* row, int col, float a, float b, float c, float d) {
+    if constexpr (__is_same(OutT, f16s_t)) {
+        f16s_store4(reinterpret_cast<unsigned short*>(row), col, a * SWC_F16S_ACT_SCALE, b * SWC_F16S_ACT_SCALE,
+                    c * SWC_F16S_ACT_SCALE, d * SWC_F16S_ACT_SCALE);
+    } else {
+        store4<OutT>(row + col, a, b, c, d);
+    }
+}
+template <typename OutT>
+__device__ __forceinline__ long row_units(long C) { return __is_same(OutT, f16s_t) ? 2 * C : C; }
+
 // ------------------------------------------------------------------ LayerNorm
 constexpr int LN_MAXV = 8;  // float4 per lane => C <= 2048
 
@@ -40,10 +54,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (r >= rows) return;
     const int b = (int)(r / tw), t = (int)(r - (long)b * tw);
     const float* xr = x + ((long)b * t_in + t) * C;
-    OutT* yr = y + ((long)b * t_out + t) * C;
+    OutT* yr = y + ((long)b * t_out + t) * row_units<OutT>(C);
     const int nv = C >> 2;  // float4 count
     if (lens && t >= lens[b]) {
-        for (int i = lane; i < nv; i += 64) store4<OutT>(yr + 4 * i, 0.f, 0.f, 0.f, 0.f);
+        for (int i = lane; i < nv; i += 64) store_row4<OutT>(yr, 4 * i, 0.f, 0.f, 0.f, 0.f);
         return;
     }
     float4 v[LN_MAXV];
@@ -74,8 +88,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if (i < nv) {
             const float4 ww = *reinterpret_cast<const float4*>(w + 4 * i);
             const float4 bb = *reinterpret_cast<const float4*>(bia + 4 * i);
-            store4<OutT>(yr + 4 * i, (v[k].x - mean) * rstd * ww.x + bb.x, (v[k].y - mean) * rstd * ww.y + bb.y,
-                         (v[k].z - mean) * rstd * ww.z + bb.z, (v[k].w - mean) * rstd * ww.w + bb.w);
+            store_row4<OutT>(yr, 4 * i, (v[k].x - mean) * rstd * ww.x + bb.x, (v[k].y - mean) * rstd * ww.y + bb.y,
+                             (v[k].z - mean) * rstd * ww.z + bb.z, (v[k].w - mean) * rstd * ww.w + bb.w);
         }
     }
 }
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
     const int b = blockIdx.z;
     const int t0 = blockIdx.y * SN_TS;
     const float* xc = x + (long)b * T * C + c;
-    OutT* yc = y + (long)b * T * C + c;
+    OutT* yb = y + (long)b * T * row_units<OutT>(C);
     const float al = alpha[c];
     const float ib = 1.0f / (beta[c] + 1e-9f);
     const int T2 = 2 * T;
@@ -213,7 +227,15 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
             const float av = (m & 1) ? A1[m >> 1] : A0[m >> 1];
             o += av * F.f[k];
         }
-        store_out<OutT>(yc + (long)t * C, o);
+        if constexpr (__is_same(OutT, f16s_t)) {
+            unsigned short hi, lo;
+            f16s_split(o * SWC_F16S_ACT_SCALE, hi, lo);
+            unsigned short* rp = reinterpret_cast<unsigned short*>(yb) + (long)t * 2 * C + f16s_col(c);
+            rp[0] = hi;
+            rp[32] = lo;
+        } else {
+            store_out<OutT>(yb + (long)t * C + c, o);
+        }
 #pragma unroll
         for (int k = 0; k < 6; ++k) { A0[k] = A0[k + 1]; A1[k] = A1[k + 1]; }
     }
@@ -427,6 +449,17 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict
     if (i < n) y[i] = f32_to_bf16(x[i]);
 }
 
+__global__ void cast_f16s_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ y, long rows,
+                                 int K, float scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 4 logical columns
+    const int k4 = K >> 2;
+    if (i >= rows * k4) return;
+    const long r = i / k4;
+    const int k = (int)(i - r * k4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + k);
+    f16s_store4(y + r * 2L * K, k, v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+}
+
 inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 }  // namespace
@@ -435,22 +468,29 @@ inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
     do {                                      \
         if ((dt) == SWC_BF16) { CALL_BF16; } else { CALL_F32; } \
     } while (0)
+#define OUT_DISPATCH3(dt, CALL_F32, CALL_BF16, CALL_F16S)                                        \
+    do {                                                                                         \
+        if ((dt) == SWC_BF16) { CALL_BF16; } else if ((dt) == SWC_F16S) { CALL_F16S; } else { CALL_F32; } \
+    } while (0)
 
 extern "C" int swc_layernorm(const float* x, void* y, const float* w, const float* b, const int32_t* lens,
                              int32_t B, int32_t t_in, int32_t t_out, int32_t C, float eps, int32_t y_dtype,
                              void* stream) {
     SWC_CHECK_ARG(x && y && w && b, "swc_layernorm: null pointer");
     SWC_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * LN_MAXV, "swc_layernorm: C=%d unsupported", C);
-    SWC_CHECK_ARG(y_dtype == SWC_F32 || y_dtype == SWC_BF16, "swc_layernorm: bad dtype");
+    SWC_CHECK_ARG(y_dtype == SWC_F32 || y_dtype == SWC_BF16 || y_dtype == SWC_F16S, "swc_layernorm: bad dtype");
+    SWC_CHECK_ARG(y_dtype != SWC_F16S || C % 32 == 0, "swc_layernorm: split-f16 output needs C % 32 == 0");
     const int tw = t_in < t_out ? t_in : t_out;
     const long rows = (long)B * tw;
     if (rows <= 0) return SWC_OK;
     hipStream_t s = (hipStream_t)stream;
-    OUT_DISPATCH(y_dtype,
-                 hipLaunchKernelGGL(layernorm_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (float*)y, w,
-                                    b, lens, rows, tw, t_in, t_out, C, eps),
-                 hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (bf16_t*)y,
-                                    w, b, lens, rows, tw, t_in, t_out, C, eps));
+    OUT_DISPATCH3(y_dtype,
+                  hipLaunchKernelGGL(layernorm_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (float*)y, w,
+                                     b, lens, rows, tw, t_in, t_out, C, eps),
+                  hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (bf16_t*)y,
+                                     w, b, lens, rows, tw, t_in, t_out, C, eps),
+                  hipLaunchKernelGGL(layernorm_kernel<f16s_t>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (f16s_t*)y,
+                                     w, b, lens, rows, tw, t_in, t_out, C, eps));
     SWC_CHECK_LAUNCH("swc_layernorm");
     return SWC_OK;
 }
@@ -477,17 +517,18 @@ extern "C" int swc_snake_aa(const float* x, void* y, const float* alpha, const f
                             const float* filt_host12, int32_t B, int32_t T, int32_t C, int32_t y_dtype,
                             void* stream) {
     SWC_CHECK_ARG(x && y && alpha && beta && filt_host12, "swc_snake_aa: null pointer");
-    SWC_CHECK_ARG(y_dtype == SWC_F32 || y_dtype == SWC_BF16, "swc_snake_aa: bad dtype");
+    SWC_CHECK_ARG(y_dtype == SWC_F32 || y_dtype == SWC_BF16 || y_dtype == SWC_F16S, "swc_snake_aa: bad dtype");
+    SWC_CHECK_ARG(y_dtype != SWC_F16S || C % 32 == 0, "swc_snake_aa: split-f16 output needs C % 32 == 0");
     SWC_CHECK_ARG(B <= 65535, "swc_snake_aa: B too large");
     if (B <= 0 || T <= 0 || C <= 0) return SWC_OK;
     Filt12 F;
     for (int i = 0; i < 12; ++i) F.f[i] = filt_host12[i];
     dim3 grid(nblk(C, 256), nblk(T, SN_TS), B);
     hipStream_t s = (hipStream_t)stream;
-    OUT_DISPATCH(y_dtype,
-                 hipLaunchKernelGGL(snake_aa_kernel<float>, grid, dim3(256), 0, s, x, (float*)y, alpha, beta, F, T, C),
-                 hipLaunchKernelGGL(snake_aa_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)y, alpha, beta, F, T,
-                                    C));
+    OUT_DISPATCH3(y_dtype,
+                  hipLaunchKernelGGL(snake_aa_kernel<float>, grid, dim3(256), 0, s, x, (float*)y, alpha, beta, F, T, C),
+                  hipLaunchKernelGGL(snake_aa_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)y, alpha, beta, F, T, C),
+                  hipLaunchKernelGGL(snake_aa_kernel<f16s_t>, grid, dim3(256), 0, s, x, (f16s_t*)y, alpha, beta, F, T, C));
     SWC_CHECK_LAUNCH("swc_snake_aa");
     return SWC_OK;
 }
@@ -612,6 +653,18 @@ extern "C" int swc_istft_ola(const float* frames, const float* window_sq, float*
     hipLaunchKernelGGL(istft_ola_kernel, dim3(nblk((long)T * 160, 256), B), dim3(256), 0, (hipStream_t)stream,
                        frames, window_sq, wav, T);
     SWC_CHECK_LAUNCH("swc_istft_ola");
+    return SWC_OK;
+}
+
+extern "C" int swc_cast_f32_f16s(const float* x, int64_t ldx, void* y, int64_t rows, int32_t K, float scale,
+                                 void* stream) {
+    SWC_CHECK_ARG(x && y, "swc_cast_f32_f16s: null pointer");
+    SWC_CHECK_ARG(K > 0 && K % 32 == 0 && ldx >= K && ldx % 4 == 0 && aligned16(x) && aligned16(y),
+                  "swc_cast_f32_f16s: K=%d must be a multiple of 32, rows 16-byte aligned", K);
+    if (rows <= 0) return SWC_OK;
+    hipLaunchKernelGGL(cast_f16s_kernel, dim3(nblk(rows * (K / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
+                       (unsigned short*)y, (long)rows, K, scale == 0.0f ? 1.0f : scale);
+    SWC_CHECK_LAUNCH("swc_cast_f32_f16s");
     return SWC_OK;
 }
 

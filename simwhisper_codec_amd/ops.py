@@ -8,9 +8,15 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, BF16, F32  # noqa: F401
+from ._lib import ACT_GELU, ACT_NONE, BF16, F16S, F16S_ACT_SCALE, F32  # noqa: F401
 
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+# torch.float16 tensors carry the split-f16 format (SWC_F16S): last dim = 2 x logical columns
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16S}
+
+
+def _w(dtype, cols):
+    """storage width (tensor columns) of `cols` logical columns"""
+    return 2 * cols if dtype == torch.float16 else cols
 
 # Optional per-launch timing hook (bench.py): an object with begin(kind, work) / end(), called
 # around every swc_gemm launch on the launching stream.  None in normal operation.
@@ -34,17 +40,21 @@ def _chk(t, name, dtype=None):
 
 
 def gemm(A, W, M, N, K, *, out=None, out_dtype=None, lda=None, ldw=None, ldc=None, bias=None, gamma=None,
-         residual=None, ldr=None, act=ACT_NONE, taps=1, dil=1, stride=1, pad=0, t_in=None, t_out=None):
-    """C[M, N] = epi(A (*) W^T); see include/swc.h swc_gemm.  A: [.., lda], W: [N, ldw]."""
+         residual=None, ldr=None, act=ACT_NONE, taps=1, dil=1, stride=1, pad=0, t_in=None, t_out=None, alpha=1.0,
+         out_scale=1.0):
+    """C[M, N] = epi(A (*) W^T); see include/swc.h swc_gemm.  A: [.., lda], W: [N, ldw].
+    float16 tensors are split-f16 (2 halves per logical column); lda/ldw/ldc are LOGICAL columns."""
     lib = _lib.load()
     _chk(A, "gemm A"); _chk(W, "gemm W")
     if A.dtype != W.dtype:
         raise _lib.SwcError(f"gemm: A is {A.dtype} but W is {W.dtype}")
-    lda = A.stride(-2) if lda is None else lda
-    ldw = W.stride(-2) if ldw is None else ldw
+    sa = 2 if A.dtype == torch.float16 else 1
+    lda = A.stride(-2) // sa if lda is None else lda
+    ldw = W.stride(-2) // sa if ldw is None else ldw
     if out is None:
-        out = torch.empty((M, N), device=A.device, dtype=out_dtype or torch.float32)
-    ldc = out.stride(-2) if ldc is None else ldc
+        od = out_dtype or torch.float32
+        out = torch.empty((M, _w(od, N)), device=A.device, dtype=od)
+    ldc = out.stride(-2) // (2 if out.dtype == torch.float16 else 1) if ldc is None else ldc
     a = _lib.GemmArgs()
     a.A, a.W, a.C = A.data_ptr(), W.data_ptr(), out.data_ptr()
     a.bias = bias.data_ptr() if bias is not None else None
@@ -59,22 +69,31 @@ def gemm(A, W, M, N, K, *, out=None, out_dtype=None, lda=None, ldw=None, ldc=Non
     if M == 0:
         return out
     a.a_dtype, a.c_dtype, a.act = _DT[A.dtype], _DT[out.dtype], act
+    a.alpha, a.out_scale = alpha, out_scale
     prof = PROFILER
     if prof is not None:
-        prof.begin("gemm_bf16" if A.dtype == torch.bfloat16 else "gemm_f32", 2.0 * M * N * K * taps)
+        prof.begin({torch.bfloat16: "gemm_bf16", torch.float16: "gemm_f16s"}.get(A.dtype, "gemm_f32"),
+                   2.0 * M * N * K * taps)
     _lib.check(lib.swc_gemm(C.byref(a), _stream()), "swc_gemm")
     if prof is not None:
         prof.end()
     return out
 
 
-def attention(qkv, lens, B, T, H, out=None):
+def attention(qkv, lens, B, T, H, out=None, out_dtype=None):
+    """out_dtype None: same element type as qkv.  torch.float16: f32 qkv in, split-f16 out."""
     lib = _lib.load()
     _chk(qkv, "attention qkv"); _chk(lens, "attention lens", torch.int32)
+    od = out_dtype or qkv.dtype
     if out is None:
-        out = torch.empty((B, T, H * 64), device=qkv.device, dtype=qkv.dtype)
-    _lib.check(lib.swc_attention(_ptr(qkv), _ptr(out), _ptr(lens), B, T, H, _DT[qkv.dtype], _stream()),
-               "swc_attention")
+        out = torch.empty((B, T, _w(od, H * 64)), device=qkv.device, dtype=od)
+    if od == qkv.dtype:
+        _lib.check(lib.swc_attention(_ptr(qkv), _ptr(out), _ptr(lens), B, T, H, _DT[qkv.dtype], _stream()),
+                   "swc_attention")
+    else:
+        _chk(qkv, "attention qkv", torch.float32)
+        _lib.check(lib.swc_attention_ex(_ptr(qkv), _ptr(out), _ptr(lens), B, T, H, _DT[od], _stream()),
+                   "swc_attention_ex")
     return out
 
 
@@ -83,7 +102,7 @@ def layernorm(x, w, b, eps, *, B, t_in, C_, t_out=None, lens=None, out=None, out
     _chk(x, "layernorm x", torch.float32)
     t_out = t_in if t_out is None else t_out
     if out is None:
-        out = torch.empty((B, t_out, C_), device=x.device, dtype=out_dtype)
+        out = torch.empty((B, t_out, _w(out_dtype, C_)), device=x.device, dtype=out_dtype)
     _lib.check(lib.swc_layernorm(_ptr(x), _ptr(out), _ptr(w), _ptr(b), _ptr(lens), B, t_in, t_out, C_, eps,
                                  _DT[out.dtype], _stream()), "swc_layernorm")
     return out
@@ -104,7 +123,7 @@ def snake_aa(x, alpha, beta, filt12, *, B, T, C_, out=None, out_dtype=torch.floa
     lib = _lib.load()
     _chk(x, "snake_aa x", torch.float32)
     if out is None:
-        out = torch.empty((B, T, C_), device=x.device, dtype=out_dtype)
+        out = torch.empty((B, T, _w(out_dtype, C_)), device=x.device, dtype=out_dtype)
     f = (C.c_float * 12)(*[float(v) for v in filt12])
     _lib.check(lib.swc_snake_aa(_ptr(x), _ptr(out), _ptr(alpha), _ptr(beta), f, B, T, C_, _DT[out.dtype],
                                 _stream()), "swc_snake_aa")
@@ -189,4 +208,15 @@ def cast_bf16(x):
     x = x.contiguous()
     y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
     _lib.check(lib.swc_cast_f32_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "swc_cast_f32_bf16")
+    return y
+
+
+def cast_f16s(x, K, scale=F16S_ACT_SCALE, ldx=None):
+    """f32 [rows, >=K] -> split-f16 [rows, 2K] (float16 storage), x * scale split into hi/lo halves."""
+    lib = _lib.load()
+    _chk(x, "cast_f16s x", torch.float32)
+    rows = x.numel() // x.shape[-1]
+    ldx = x.stride(-2) if ldx is None else ldx
+    y = torch.empty((rows, 2 * K), device=x.device, dtype=torch.float16)
+    _lib.check(lib.swc_cast_f32_f16s(_ptr(x), ldx, _ptr(y), rows, K, scale, _stream()), "swc_cast_f32_f16s")
     return y

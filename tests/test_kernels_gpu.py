@@ -358,3 +358,90 @@ def test_errors_are_loud():
         ops.gemm(A, A, 4, 4, 6)  # K not a multiple of 4
     with pytest.raises(SwcError):
         ops.gemm(A.cpu(), A.cpu(), 4, 4, 4)
+
+
+# ----------------------------------------------------------------------------- split-f16 (SWC_F16S)
+def _unsplit(t, K, scale):
+    """split-f16 [rows, 2K] -> float64 [rows, K]"""
+    v = t.cpu().double().view(-1, K // 32, 2, 32)
+    return ((v[:, :, 0] + v[:, :, 1]).reshape(-1, K)) / scale
+
+
+def test_f16s_cast_roundtrip():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(37, 96, generator=g) * torch.logspace(-4, 1, 96)[None, :]
+    y = ops.cast_f16s(x.to(DEV), 96, scale=64.0)
+    back = _unsplit(y, 96, 64.0)
+    # 22 significand bits; absolute floor from fp16 subnormals (2^-25 / scale)
+    err = (back - x.double()).abs()
+    assert (err <= x.double().abs() * 2.0 ** -21 + 2.0 ** -24 / 64).all()
+    big = torch.full((1, 32), 5000.0)
+    assert torch.isfinite(_unsplit(ops.cast_f16s(big.to(DEV), 32, scale=64.0), 32, 64.0)).all()  # saturates, no inf
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 256), (1000, 768, 768), (257, 96, 3072)])
+def test_gemm_f16s_is_f32_class(M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.03
+    bias = torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T + bias.double()
+    sa, sw = 64.0, 2.0 ** 14
+    As, Ws = ops.cast_f16s(A.to(DEV), K, scale=sa), ops.cast_f16s(W.to(DEV), K, scale=sw)
+    out = ops.gemm(As, Ws, M, N, K, bias=bias.to(DEV), alpha=1.0 / (sa * sw))
+    e_split = _rel(out, ref)
+    e_f32 = _rel(ops.gemm(A.to(DEV), W.to(DEV), M, N, K, bias=bias.to(DEV)), ref)
+    assert e_split < 2e-6, (e_split, e_f32)
+    assert e_split < 4 * e_f32 + 2e-7, (e_split, e_f32)
+    # split-f16 output + GELU epilogue (exact erf) + residual
+    if N % 32 == 0:
+        res = torch.randn(M, N, generator=g)
+        o2 = ops.gemm(As, Ws, M, N, K, bias=bias.to(DEV), alpha=1.0 / (sa * sw), act=ops.ACT_GELU, residual=res.to(DEV),
+                      out_dtype=torch.float16, out_scale=64.0)
+        want = torch.nn.functional.gelu(ref) + res.double()
+        assert float((_unsplit(o2, N, 64.0) - want).abs().max() / want.abs().max()) < 3e-6
+
+
+def test_gemm_f16s_conv_taps():
+    ops = _ops()
+    B, T, Cin, Cout, k, dil = 3, 77, 64, 96, 7, 3
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, k, generator=g) / 20
+    ref = F.conv1d(x.double(), w.double(), padding=3 * dil, dilation=dil)
+    xs = ops.cast_f16s(x.transpose(1, 2).contiguous().view(B * T, Cin).to(DEV), Cin, scale=64.0)
+    # weights: every tap is its own run of Cin logical columns (K % 32 == 0), split per row
+    wp = w.permute(0, 2, 1).contiguous().view(Cout, k * Cin)
+    ws = ops.cast_f16s(wp.to(DEV), k * Cin, scale=1024.0)
+    out = ops.gemm(xs, ws, B * T, Cout, Cin, lda=Cin, ldw=k * Cin, taps=k, dil=dil, pad=3 * dil, t_in=T, t_out=T,
+                   alpha=1.0 / (64.0 * 1024.0))
+    assert _rel(out.view(B, T, Cout).transpose(1, 2), ref) < 2e-6
+
+
+def test_f16s_producers():
+    ops = _ops()
+    B, T, C = 2, 50, 128
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B, T, C, generator=g) * 2
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    lens = torch.tensor([50, 20], dtype=torch.int32)
+    y = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, B=B, t_in=T, C_=C, lens=lens.to(DEV), out_dtype=torch.float16)
+    ref = F.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-5)
+    ref[1, 20:] = 0
+    assert (_unsplit(y, C, 64.0).view(B, T, C) - ref).abs().max().item() < 1e-5
+    # attention with split output equals the f32 output to 2^-21
+    H = 2
+    qkv = torch.randn(B, T, 3 * H * 64, generator=g) * 0.5
+    o32 = ops.attention(qkv.to(DEV), lens.to(DEV), B, T, H)
+    o16 = ops.attention(qkv.to(DEV), lens.to(DEV), B, T, H, out_dtype=torch.float16)
+    a, bb = _unsplit(o16, H * 64, 64.0).view(B, T, -1), o32.cpu().double()
+    for i, L in enumerate(lens.tolist()):
+        assert (a[i, :L] - bb[i, :L]).abs().max().item() < 2e-6
+    # snake
+    al, be = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    f = _kaiser_sinc12()
+    s32 = ops.snake_aa(x.to(DEV), al.exp().to(DEV), be.exp().to(DEV), f.tolist(), B=B, T=T, C_=C)
+    s16 = ops.snake_aa(x.to(DEV), al.exp().to(DEV), be.exp().to(DEV), f.tolist(), B=B, T=T, C_=C, out_dtype=torch.float16)
+    assert (_unsplit(s16, C, 64.0).view(B, T, C) - s32.cpu().double()).abs().max().item() < 2e-6

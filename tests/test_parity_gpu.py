@@ -41,11 +41,12 @@ def _relerr(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12)) if a.size else 0.0
 
 
+@pytest.mark.parametrize("precision", ["fp32", "mixed"])
 @pytest.mark.parametrize("tag", ["tiny", "real"])
 @pytest.mark.parametrize("name", ["single", "ragged"])
-def test_tokenize_stages(tag, name):
+def test_tokenize_stages(tag, name, precision):
     g = golden(tag, name)
-    m = model(tag, "fp32")
+    m = model(tag, precision)
     wavs = golden_audio(g)
     n = [len(w) for w in wavs]
     x = torch.zeros(len(wavs), 1, max(n))
@@ -56,17 +57,18 @@ def test_tokenize_stages(tag, name):
     assert np.array_equal(r["codes_lengths"].cpu().numpy(), g["st_code_lens"])
     codes = r["codes"].cpu().numpy()
     mism = int((codes != g["st_codes"]).sum())
-    _report(f"tokenize/{tag}/{name}", code_mismatch=mism, total=codes.size,
+    _report(f"tokenize/{tag}/{name}/{precision}", code_mismatch=mism, total=codes.size,
             zq_err=float(np.abs(r["zq"].cpu().numpy() - g["st_zq"]).max()))
     assert mism == 0
     assert np.array_equal(r["zq"].cpu().numpy(), g["st_zq"])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "mixed"])  # mixed = split-f16 encoder (3 f16 MFMAs, f32-class)
 @pytest.mark.parametrize("tag", ["tiny", "real"])
 @pytest.mark.parametrize("name", ["single", "ragged", "zeros", "short", "chunked"])
-def test_encode_codes_bit_exact(tag, name):
+def test_encode_codes_bit_exact(tag, name, precision):
     g = golden(tag, name)
-    m = model(tag, "fp32")
+    m = model(tag, precision)
     wavs = [w.to(DEV) for w in golden_audio(g)]
     enc = m.encode(wavs, overlap_seconds=10)
     tot = mism = 0
@@ -74,7 +76,7 @@ def test_encode_codes_bit_exact(tag, name):
         want = g[f"codes_{i}"]
         assert tuple(c.shape) == want.shape, (c.shape, want.shape)
         mism += int((c.cpu().numpy() != want).sum()); tot += want.size
-    _report(f"encode/{tag}/{name}", code_mismatch=mism, total=tot)
+    _report(f"encode/{tag}/{name}/{precision}", code_mismatch=mism, total=tot)
     assert mism == 0
 
 
