@@ -103,7 +103,15 @@ int swc_gemm(const swc_gemm_args* args, void* stream);
  */
 int swc_attention(const void* qkv, void* out, const int32_t* lens, int32_t B, int32_t T,
                   int32_t H, int32_t dtype, void* stream);
-/* same with f32 qkv in and the output written as out_dtype (F32 | F16S at SWC_F16S_ACT_SCALE) */
+/*
+ * 16-bit operand attention (same semantics): dtype BF16 = bf16 q/k/v in, bf16 out, on the bf16 MFMA;
+ * dtype F16S = split-f16 q/k/v in (SWC_F16S_ACT_SCALE), split-f16 out, three f16 MFMAs per product
+ * (f32-class scores and outputs).  128 queries per workgroup, K/V tiles double-buffered by LDS-DMA,
+ * V^T operand through ds_read_b64_tr_b16.
+ */
+int swc_attention16(const void* qkv, void* out, const int32_t* lens, int32_t B, int32_t T, int32_t H,
+                    int32_t dtype, void* stream);
+/* f32 qkv in and the output written as out_dtype (F32 | F16S at SWC_F16S_ACT_SCALE), exact-f32 MFMA */
 int swc_attention_ex(const void* qkv, void* out, const int32_t* lens, int32_t B, int32_t T, int32_t H,
                      int32_t out_dtype, void* stream);
 

@@ -42,6 +42,7 @@ SIGNATURES = {
     "swc_gemm": [C.POINTER(GemmArgs), _P],
     "swc_attention": [_P, _P, _P, _I, _I, _I, _I, _P],
     "swc_attention_ex": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "swc_attention16": [_P, _P, _P, _I, _I, _I, _I, _P],
     "swc_layernorm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "swc_dwconv7_ln": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
     "swc_snake_aa": [_P, _P, _P, _P, C.POINTER(_F), _I, _I, _I, _I, _P],

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libswc_hip.so")
-SOURCES = ["swc_api.hip", "swc_gemm.hip", "swc_attention.hip", "swc_pointwise.hip"]
+SOURCES = ["swc_api.hip", "swc_gemm.hip", "swc_attention.hip", "swc_attention16.hip", "swc_pointwise.hip"]
 ARCH = "gfx950"
 
 

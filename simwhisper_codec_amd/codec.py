@@ -313,12 +313,10 @@ class AudioCodec(nn.Module):
         """12 x OmniWhisperTransformerLayer (modules.py:214-232). h: [B*T, D] f32 residual stream (updated in place)."""
         D = h.shape[-1]
         M = B * T
-        # q/k/v feed the attention kernel, which reads f32 or bf16 (split-f16 is a GEMM-operand format only)
-        qdt = torch.float32 if dt == torch.float16 else dt
         for L in layers:
             x = ops.layernorm(h, L.ln1[0], L.ln1[1], 1e-5, B=B, t_in=T, C_=D, out_dtype=dt)
-            qkv = self._mm(x, L.wqkv, M, 3 * D, D, lda=D, bias=L.bqkv, out_dtype=qdt)
-            a = ops.attention(qkv, lens, B, T, H, out_dtype=dt)
+            qkv = self._mm(x, L.wqkv, M, 3 * D, D, lda=D, bias=L.bqkv, out_dtype=dt)
+            a = ops.attention(qkv, lens, B, T, H)
             self._mm(a, L.wo, M, D, D, lda=D, bias=L.bo, residual=h, out=h)
             x = ops.layernorm(h, L.ln2[0], L.ln2[1], 1e-5, B=B, t_in=T, C_=D, out_dtype=dt)
             F_ = L.b1.shape[0]

@@ -1,0 +1,317 @@
+// swc_attention (16-bit operand paths): varlen, non-causal, head_dim 64 flash attention on the
+// 16x16x32 MFMAs.
+//   PLANES = 1: bf16 q/k/v, v_mfma_f32_16x16x32_bf16, bf16 output            (decode side)
+//   PLANES = 2: split-f16 q/k/v (SWC_F16S, scale 64), three f16 MFMAs per product
+//               (hi*hi + hi*lo + lo*hi, f32 accumulate): f32-class scores and outputs at 3/16
+//               of the exact-f32 MFMA cycles; split-f16 output                (encode side)
+// One workgroup = 128 queries of one (utterance, head); each of its 4 waves owns 32 queries (two
+// 16-query MFMA tiles that share every K/V fragment) and walks the valid keys in tiles of 64,
+// K/V tiles double-buffered in LDS by LDS-DMA.
+//
+// As in the f32 kernel the score tile is computed transposed (S^T = K Q^T): its C/D fragment is
+// already the B operand of O^T = V^T P^T once two 16-key tiles are packed into one 32-deep k-step
+// (k index 8h+j  <->  key 16 t0 + 4h + j for j < 4, 16 t1 + 4h + j - 4 otherwise).  The matching
+// V^T operand (4 consecutive keys of one channel) comes out of the row-major V tile through
+// ds_read_b64_tr_b16, the hardware transposing read.
+#include "swc_common.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16a[4] = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void glds16a(const void* gsrc, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_addr)
+        : "memory");
+}
+
+template <int PLANES>
+__device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 c) {
+    if constexpr (PLANES == 1)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                       *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&a),
+                                                      *reinterpret_cast<const f16x8*>(&b), c, 0, 0, 0);
+}
+
+constexpr int QB16 = 128;  // queries per workgroup
+constexpr int KT16 = 64;   // keys per tile
+
+template <int PLANES>
+__global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__ qkv, unsigned short* __restrict__ out,
+                                                        const int* __restrict__ lens, int T, int H) {
+    constexpr int ROWB = 128 * PLANES;    // bytes of one (token, head) row: 64 bf16, or [32 hi|32 lo|32 hi|32 lo] f16
+    constexpr int CPR = ROWB / 16;        // 16-byte chunks per row
+    constexpr int TILE = KT16 * ROWB;     // bytes of a K or V tile
+    constexpr int NI = TILE / 1024;       // LDS-DMA wave-instructions per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
+
+    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * QB16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fh = lane >> 4;
+    const int D = H * 64;
+    const long ldb = 3L * D * 2 * PLANES;  // bytes per token row of qkv
+    const long part = (long)D * 2 * PLANES;  // byte offset between the q, k and v parts
+    int len = lens[b];
+    len = len < 0 ? 0 : (len > T ? T : len);
+    const char* base = qkv + (long)b * T * ldb + (long)head * ROWB;
+
+    auto krow_swz = [](int row) { return PLANES == 1 ? (((row >> 1) ^ ((row >> 4) << 1)) & 7) : (row & 15); };
+    auto vrow_swz = [](int row) { return PLANES == 1 ? ((row >> 1) & 3) : (row & 7); };
+
+    // ---- output addressing
+    auto store_o = [&](int q, int d, float a, float bq, float c, float e) {
+        if (q >= T) return;
+        if constexpr (PLANES == 1) {
+            uint2 u;
+            u.x = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(bq) << 16);
+            u.y = (unsigned)f32_to_bf16(c) | ((unsigned)f32_to_bf16(e) << 16);
+            *reinterpret_cast<uint2*>(out + ((long)b * T + q) * D + head * 64 + d) = u;
+        } else {
+            f16s_store4(out + ((long)b * T + q) * 2L * D, head * 64 + d, a, bq, c, e);
+        }
+    };
+
+    if (q0 >= len) {  // whole block is padding: defined, finite output
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) store_o(q0 + wave * 32 + qt * 16 + fr, dt * 16 + fh * 4, 0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+
+    // ---- Q fragments (B operand of S^T): [qt][g][plane]
+    uint4 qf[2][2][PLANES];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        int q = q0 + wave * 32 + qt * 16 + fr;
+        q = q < T ? q : T - 1;
+        const char* qp = base + (long)q * ldb;
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl) {
+                const int c = PLANES == 1 ? (4 * g + fh) : (8 * g + 4 * pl + fh);
+                qf[qt][g][pl] = *reinterpret_cast<const uint4*>(qp + 16 * c);
+            }
+    }
+
+    // ---- staging geometry (LDS-DMA, lane-linear 1 KiB per wave-instruction, swizzle on the source)
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int l_row = lane / CPR, l_pos = lane % CPR;
+    auto stage = [&](int kt, int st) {
+        const int k0 = kt * KT16;
+        const char* zero = reinterpret_cast<const char*>(g_zero16a);
+#pragma unroll
+        for (int j = 0; j < NI / 4; ++j) {
+            const int inst = wave_u + 4 * j;
+            const int row = inst * (64 / CPR) + l_row;
+            const int key = k0 + row;
+            const bool ok = key < len;
+            const char* rp = base + (long)(ok ? key : 0) * ldb;
+            const int kc = l_pos ^ krow_swz(row);
+            const int vu = (l_pos >> 1) ^ vrow_swz(row);
+            const char* ks = rp + part + 16 * kc;
+            const char* vs = rp + 2 * part + 16 * ((vu << 1) | (l_pos & 1));
+            glds16a(ok ? ks : zero, smem_base + st * 2 * TILE + inst * 1024);
+            glds16a(ok ? vs : zero, smem_base + st * 2 * TILE + TILE + inst * 1024);
+        }
+    };
+    auto fence = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    f32x4 o[2][4];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const float s_scale = PLANES == 1 ? 1.0f : 1.0f / (SWC_F16S_ACT_SCALE * SWC_F16S_ACT_SCALE);
+    constexpr float P_SCALE = 2048.0f;  // split-f16 P: keeps the lo halves of small probabilities normal
+
+    const int ntile = (len + KT16 - 1) / KT16;
+    stage(0, 0);
+    fence();
+    for (int kt = 0; kt < ntile; ++kt) {
+        const int st = kt & 1;
+        if (kt + 1 < ntile) stage(kt + 1, st ^ 1);
+        const char* sK = smem + st * 2 * TILE;
+        const char* sV = sK + TILE;
+        const int k0 = kt * KT16;
+
+        // S^T[key][q] for 4 key sub-tiles x 2 query tiles
+        f32x4 s[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int row = ks * 16 + fr;
+            uint4 kf[2][PLANES];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) {
+                    const int c = PLANES == 1 ? (4 * g + fh) : (8 * g + 4 * pl + fh);
+                    kf[g][pl] = *reinterpret_cast<const uint4*>(sK + row * ROWB + ((c ^ krow_swz(row)) << 4));
+                }
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    if constexpr (PLANES == 2) {
+                        a = mma16<PLANES>(kf[g][1], qf[qt][g][0], a);  // lo * hi
+                        a = mma16<PLANES>(kf[g][0], qf[qt][g][1], a);  // hi * lo
+                    }
+                    a = mma16<PLANES>(kf[g][0], qf[qt][g][0], a);
+                }
+                s[qt][ks] = a;
+            }
+        }
+        // mask, online softmax per query tile, P fragments
+        uint4 pf[2][2][PLANES];  // [qt][pair][plane]
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mt = -INFINITY;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = k0 + ks * 16 + fh * 4 + e;
+                    float v = s[qt][ks][e] * s_scale;
+                    v = key < len ? v : -INFINITY;
+                    s[qt][ks][e] = v;
+                    mt = fmaxf(mt, v);
+                }
+            mt = fmaxf(mt, __shfl_xor(mt, 16));
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float m_new = fmaxf(m_run[qt], mt);
+            const float alpha = PLANES == 1 ? __expf(m_run[qt] - m_new) : expf(m_run[qt] - m_new);
+            m_run[qt] = m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float pv = PLANES == 1 ? __expf(s[qt][ks][e] - m_new) : expf(s[qt][ks][e] - m_new);
+                    s[qt][ks][e] = pv;
+                    psum += pv;
+                }
+            l_run[qt] = l_run[qt] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[qt][dt] *= alpha;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                unsigned short h[8], lo[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = s[qt][2 * pr + (j >> 2)][j & 3];
+                    if constexpr (PLANES == 1) {
+                        h[j] = f32_to_bf16(pv);
+                    } else {
+                        f16s_split(pv * P_SCALE, h[j], lo[j]);
+                    }
+                }
+                pf[qt][pr][0] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16),
+                                           h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+                if constexpr (PLANES == 2)
+                    pf[qt][pr][1] = make_uint4(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16),
+                                               lo[4] | ((unsigned)lo[5] << 16), lo[6] | ((unsigned)lo[7] << 16));
+            }
+        }
+        // O^T[d][q] += V^T[d][key] P^T[key][q]
+        const int tq = fr >> 2, tp = fr & 3;  // transposing read: this lane addresses row tq, columns 4 tp .. 4 tp + 3
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint4 vf[PLANES];
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) {
+                    const int u = PLANES == 1 ? dt : ((dt >> 1) * 4 + (dt & 1) + 2 * pl);
+                    s16x4 part2[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int row = (2 * pr + t) * 16 + 4 * fh + tq;
+                        const char* ap = sV + row * ROWB + ((u ^ vrow_swz(row)) << 5) + 8 * tp;
+                        part2[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (__attribute__((address_space(3))) s16x4*)(uintptr_t)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)ap);
+                    }
+                    s16x8 full = __builtin_shufflevector(part2[0], part2[1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    vf[pl] = *reinterpret_cast<uint4*>(&full);
+                }
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) {
+                    f32x4 a = o[qt][dt];
+                    if constexpr (PLANES == 2) {
+                        a = mma16<PLANES>(vf[1], pf[qt][pr][0], a);
+                        a = mma16<PLANES>(vf[0], pf[qt][pr][1], a);
+                    }
+                    a = mma16<PLANES>(vf[0], pf[qt][pr][0], a);
+                    o[qt][dt] = a;
+                }
+            }
+        fence();
+    }
+
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        // split-f16: acc = sum (P * 2048) (V * 64); the output is written at the activation scale 64
+        const float inv = l > 0.f ? (PLANES == 1 ? 1.0f / l : 1.0f / (P_SCALE * l)) : 0.f;
+        const int q = q0 + wave * 32 + qt * 16 + fr;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const f32x4 v = o[qt][dt] * inv;
+            store_o(q, dt * 16 + fh * 4, v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+template <int PLANES>
+int launch16(const void* qkv, void* out, const int32_t* lens, int B, int T, int H, hipStream_t s) {
+    constexpr int LDS = 2 * 2 * KT16 * 128 * PLANES;
+    auto kern = attn16_kernel<PLANES>;
+    if (LDS > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e != hipSuccess) {
+                swc_set_error("swc_attention: cannot enable %d bytes of LDS: %s", LDS, hipGetErrorString(e));
+                return SWC_E_LAUNCH;
+            }
+            attr_set = true;
+        }
+    }
+    dim3 grid((T + QB16 - 1) / QB16, H, B), block(256);
+    hipLaunchKernelGGL(kern, grid, block, LDS, s, (const char*)qkv, (unsigned short*)out, lens, T, H);
+    return SWC_OK;
+}
+
+}  // namespace
+
+// dtype: SWC_BF16 (bf16 in, bf16 out) or SWC_F16S (split-f16 in at scale 64, split-f16 out at scale 64)
+extern "C" int swc_attention16(const void* qkv, void* out, const int32_t* lens, int32_t B, int32_t T, int32_t H,
+                               int32_t dtype, void* stream) {
+    SWC_CHECK_ARG(qkv && out && lens, "swc_attention16: null pointer");
+    SWC_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && B <= 65535 && H <= 65535, "swc_attention16: bad B/T/H");
+    SWC_CHECK_ARG(dtype == SWC_BF16 || dtype == SWC_F16S, "swc_attention16: dtype must be BF16 or F16S");
+    SWC_CHECK_ARG(aligned16(qkv) && aligned16(out), "swc_attention16: unaligned");
+    if (B == 0 || T == 0) return SWC_OK;
+    int rc = dtype == SWC_BF16 ? launch16<1>(qkv, out, lens, B, T, H, (hipStream_t)stream)
+                               : launch16<2>(qkv, out, lens, B, T, H, (hipStream_t)stream);
+    if (rc != SWC_OK) return rc;
+    SWC_CHECK_LAUNCH("swc_attention16");
+    return SWC_OK;
+}

@@ -445,7 +445,10 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     if (bf) {
         rc = big ? SWC_LAUNCH(SWC_BF16, 8, 2, 4) : SWC_LAUNCH(SWC_BF16, 4, 2, 2);
     } else if (fs) {
-        rc = SWC_LAUNCH(SWC_F16S, 4, 2, 2);
+        bool bigs = a->N >= 256 && big_tiles >= 96;
+        if (tile_override() == 128) bigs = false;
+        if (tile_override() == 256) bigs = true;
+        rc = bigs ? SWC_LAUNCH(SWC_F16S, 8, 2, 4) : SWC_LAUNCH(SWC_F16S, 4, 2, 2);
     } else {
         rc = SWC_LAUNCH(SWC_F32, 4, 2, 2);
     }

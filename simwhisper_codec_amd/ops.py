@@ -21,6 +21,7 @@ def _w(dtype, cols):
 # Optional per-launch timing hook (bench.py): an object with begin(kind, work) / end(), called
 # around every swc_gemm launch on the launching stream.  None in normal operation.
 PROFILER = None
+LEGACY_ATTENTION = False  # tests only: route bf16 attention through the f32-MFMA kernel
 
 
 def _stream():
@@ -87,7 +88,10 @@ def attention(qkv, lens, B, T, H, out=None, out_dtype=None):
     od = out_dtype or qkv.dtype
     if out is None:
         out = torch.empty((B, T, _w(od, H * 64)), device=qkv.device, dtype=od)
-    if od == qkv.dtype:
+    if qkv.dtype in (torch.bfloat16, torch.float16) and od == qkv.dtype and not LEGACY_ATTENTION:
+        _lib.check(lib.swc_attention16(_ptr(qkv), _ptr(out), _ptr(lens), B, T, H, _DT[qkv.dtype], _stream()),
+                   "swc_attention16")
+    elif od == qkv.dtype:
         _lib.check(lib.swc_attention(_ptr(qkv), _ptr(out), _ptr(lens), B, T, H, _DT[qkv.dtype], _stream()),
                    "swc_attention")
     else:

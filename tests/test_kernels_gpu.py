@@ -445,3 +445,45 @@ def test_f16s_producers():
     s32 = ops.snake_aa(x.to(DEV), al.exp().to(DEV), be.exp().to(DEV), f.tolist(), B=B, T=T, C_=C)
     s16 = ops.snake_aa(x.to(DEV), al.exp().to(DEV), be.exp().to(DEV), f.tolist(), B=B, T=T, C_=C, out_dtype=torch.float16)
     assert (_unsplit(s16, C, 64.0).view(B, T, C) - s32.cpu().double()).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("T,lens", [(64, [64, 1]), (100, [100, 37, 0]), (500, [500, 431]), (130, [65, 130, 64]), (129, [129])])
+@pytest.mark.parametrize("mode", ["bf16", "f16s"])
+def test_attention16(T, lens, mode):
+    ops = _ops()
+    B, H = len(lens), 3
+    g = torch.Generator().manual_seed(T + 1)
+    qkv = torch.randn(B, T, 3 * H * 64, generator=g) * 0.7
+    ld = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    if mode == "bf16":
+        qd = qkv.to(torch.bfloat16)
+        out = ops.attention(qd.to(DEV), ld, B, T, H).float().cpu().double()
+        src, tol = qd.float(), 1.5e-2
+    else:
+        qd = ops.cast_f16s(qkv.view(B * T, -1).to(DEV), 3 * H * 64).view(B, T, -1)
+        o16 = ops.attention(qd, ld, B, T, H)
+        assert o16.dtype == torch.float16
+        out = _unsplit(o16, H * 64, 64.0).view(B, T, H * 64)
+        src, tol = qkv, 1e-5
+    assert torch.isfinite(out).all()
+    q, k, v = [t.reshape(B, T, H, 64).transpose(1, 2).double() for t in src.chunk(3, dim=-1)]
+    for b, L in enumerate(lens):
+        if L == 0:
+            continue
+        s = q[b, :, :L] @ k[b, :, :L].transpose(-1, -2)
+        ref = (torch.softmax(s, -1) @ v[b, :, :L]).transpose(0, 1).reshape(L, H * 64)
+        err = (out[b, :L] - ref).abs().max().item()
+        assert err < tol, (b, L, err)
+
+
+def test_attention16_spike():
+    ops = _ops()
+    B, T, H = 1, 200, 1
+    g = torch.Generator().manual_seed(1)
+    qkv = torch.randn(B, T, 192, generator=g) * 0.3
+    qkv[0, 150, 64:128] = qkv[0, 10, 0:64] * 40.0
+    qd = ops.cast_f16s(qkv.view(T, -1).to(DEV), 192).view(B, T, -1)
+    out = _unsplit(ops.attention(qd, torch.tensor([T], dtype=torch.int32, device=DEV), B, T, H), 64, 64.0)
+    q, k, v = [t.double() for t in qkv[0].chunk(3, dim=-1)]
+    ref = torch.softmax(q @ k.T, -1) @ v
+    assert (out - ref).abs().max().item() < 1e-5

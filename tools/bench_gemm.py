@@ -13,16 +13,25 @@ SHAPES = [  # (name, M, N, K, gelu, out_bf16)
 ]
 
 def main():
-    dts = [torch.bfloat16, torch.float32] if len(sys.argv) < 2 else [dict(bf16=torch.bfloat16, f32=torch.float32)[sys.argv[1]]]
+    dts = [torch.bfloat16, torch.float32] if len(sys.argv) < 2 else [dict(bf16=torch.bfloat16, f32=torch.float32, f16s=torch.float16)[sys.argv[1]]]
     dev = "cuda"
     for dt in dts:
         tot_f = tot_t = 0.0
         for name, M, N, K, gelu, obf in SHAPES:
-            A = (torch.randn(M, K, device=dev) * 0.5).to(dt)
-            W = (torch.randn(N, K, device=dev) * 0.05).to(dt)
+            if dt == torch.float16 and K % 32:
+                continue
+            if dt == torch.float16:
+                A = ops.cast_f16s(torch.randn(M, K, device=dev) * 0.5, K)
+                W = ops.cast_f16s(torch.randn(N, K, device=dev) * 0.05, K, scale=2.0 ** 14)
+            else:
+                A = (torch.randn(M, K, device=dev) * 0.5).to(dt)
+                W = (torch.randn(N, K, device=dev) * 0.05).to(dt)
             bias = torch.randn(N, device=dev)
             ldc = (N + 7) // 8 * 8
-            out = torch.empty(M, ldc, device=dev, dtype=torch.bfloat16 if (obf and dt == torch.bfloat16) else torch.float32)
+            odt = dt if (obf and dt != torch.float32) else torch.float32
+            if odt == torch.float16 and N % 32:
+                odt = torch.float32
+            out = torch.empty(M, ldc * (2 if odt == torch.float16 else 1), device=dev, dtype=odt)
             res = None if obf else torch.randn(M, ldc, device=dev)
             kw = dict(bias=bias, out=out, ldc=ldc, act=ops.ACT_GELU if gelu else ops.ACT_NONE)
             if res is not None:
