@@ -442,6 +442,22 @@ class AudioCodec(nn.Module):
         wav = self._decode_latent(zq, lat, B, T, P)
         return {"y": wav[:, None, :], "output_length": lat_dev.long() * self.decoder_upsample_rate}
 
+    # long-form scheduling: windows of one call are independent rows, so several 30 s windows are batched into
+    # one tokenize / detokenize call (the reference loops them serially, model.py:275,340)
+    max_rows_per_call = 64
+
+    @staticmethod
+    def _stack(tensors, lens, dev, dtype):
+        """list of 1-D tensors -> zero-padded [B, max(len)] on dev (one kernel when lengths are equal)."""
+        L = max(max(lens), 1)
+        if len(set(lens)) == 1 and lens[0] > 0 and all(t.device == dev and t.dtype == dtype for t in tensors):
+            return torch.stack([t.reshape(-1) for t in tensors])
+        out = torch.zeros(len(tensors), L, device=dev, dtype=dtype)
+        for i, t in enumerate(tensors):
+            if lens[i]:
+                out[i, : lens[i]] = t.reshape(-1)
+        return out
+
     @torch.inference_mode()
     def encode(self, wav_list, overlap_seconds=10, device=torch.device("cuda")):
         """model.py:244-308: 30 s windows every (30 - overlap) s, keep the first 250 codes of each window,
@@ -456,21 +472,33 @@ class AudioCodec(nn.Module):
         n = [int(w.shape[-1]) if w.dim() else 0 for w in wav_list]
         L = max(n)
         dev = self._buffers_device() if device is None else torch.device(device)
-        wav = torch.zeros(B, max(L, 1), device=dev)
-        for i, w in enumerate(wav_list):
-            wav[i, : n[i]] = w.reshape(-1)
-        parts = []
+        wav = self._stack(wav_list, n, dev, torch.float32)
+        wins = []
         for c in range(spec.cdiv(L, dur) if L else 0):
             s0, e0 = c * dur, min(c * dur + chunk, L)
             cl = [min(max(v - s0, 0), e0 - s0) for v in n]
-            if max(cl) == 0:
-                continue
-            r = self.inference_tokenize(wav[:, None, s0:e0], cl)
+            if max(cl) > 0:
+                wins.append((s0, e0, cl))
+        if not wins:
+            return {"codes_list": [torch.zeros(self.num_groups, 0, device=dev, dtype=torch.long) for _ in range(B)]}
+        parts = []
+        per_call = max(1, self.max_rows_per_call // B)
+        for w0 in range(0, len(wins), per_call):
+            grp = wins[w0:w0 + per_call]
+            if len(grp) == 1:
+                s0, e0, cl = grp[0]
+                x, lens = wav[:, None, s0:e0], cl
+            else:  # rows of different windows are independent: one call, rows = windows x utterances
+                wl = max(e0 - s0 for s0, e0, _ in grp)
+                x = torch.zeros(len(grp) * B, 1, wl, device=dev)
+                for k, (s0, e0, _) in enumerate(grp):
+                    x[k * B:(k + 1) * B, 0, : e0 - s0] = wav[:, s0:e0]
+                lens = [v for _, _, cl in grp for v in cl]
+            r = self.inference_tokenize(x, lens)
             # codes beyond an utterance's length are already zero (FSQ kernel masks them, quantizer.py:193-196);
             # keeping the first `keep` frames of every window reproduces model.py:291-297 without the copy loop
-            parts.append(r["codes"][:, :, :keep])
-        if not parts:
-            return {"codes_list": [torch.zeros(self.num_groups, 0, device=dev, dtype=torch.long) for _ in range(B)]}
+            for k in range(len(grp)):
+                parts.append(r["codes"][:, k * B:(k + 1) * B, :keep])
         allc = torch.cat(parts, dim=-1) if len(parts) > 1 else parts[0]
         return {"codes_list": [allc[:, i, : n[i] // rate] for i in range(B)]}
 
@@ -493,20 +521,40 @@ class AudioCodec(nn.Module):
         dev = self._buffers_device() if device is None else torch.device(device)
         if L == 0:
             return {"syn_wav_list": [torch.zeros(0, device=dev) for _ in range(B)]}
-        codes = torch.zeros(self.num_groups, B, L, device=dev, dtype=torch.long)
-        for i, c in enumerate(codes_list):
-            codes[:, i, : n[i]] = c.to(dev)
-        parts = []
+        if len(set(n)) == 1 and n[0] == L and all(c.device == dev for c in codes_list):
+            codes = torch.stack([c.to(torch.long) for c in codes_list], dim=1)
+        else:
+            codes = torch.zeros(self.num_groups, B, L, device=dev, dtype=torch.long)
+            for i, c in enumerate(codes_list):
+                codes[:, i, : n[i]] = c.to(dev)
+        wins = []
         for c in range(spec.cdiv(L, step)):
             s0, e0 = c * step, min(c * step + win, L)
             cl = [min(max(v - s0, 0), e0 - s0) for v in n]
-            if max(cl) == 0:
-                continue
-            r = self.inference_detokenize(codes[:, :, s0:e0].contiguous(), cl)
-            # samples beyond an utterance's valid length fall after its final trim (n_i * 1280), so the
-            # zero-fill of model.py:356-360 is unobservable: keep the first `keep` samples of each window
-            parts.append(r["y"][:, 0, :keep])
-        wav = torch.cat(parts, dim=-1) if len(parts) > 1 else parts[0]
+            if max(cl) > 0:
+                wins.append((c, s0, e0, cl))
+        # windows of EQUAL padded length are independent rows of one call; a shorter (last) window must keep its
+        # own padded length, because the un-masked up-sampler / Vocos see that boundary
+        parts = {}
+        per_call = max(1, self.max_rows_per_call // B)
+        by_len = {}
+        for wdw in wins:
+            by_len.setdefault(wdw[2] - wdw[1], []).append(wdw)
+        for tlen, ws in by_len.items():
+            for w0 in range(0, len(ws), per_call):
+                grp = ws[w0:w0 + per_call]
+                if len(grp) == 1:
+                    cg, lens = codes[:, :, grp[0][1]:grp[0][2]].contiguous(), grp[0][3]
+                else:
+                    cg = torch.cat([codes[:, :, s0:e0] for _, s0, e0, _ in grp], dim=1)
+                    lens = [v for *_, cl in grp for v in cl]
+                y = self.inference_detokenize(cg, lens)["y"]
+                # samples beyond an utterance's valid length fall after its final trim (n_i * 1280), so the
+                # zero-fill of model.py:356-360 is unobservable: keep the first `keep` samples of each window
+                for k, wdw in enumerate(grp):
+                    parts[wdw[0]] = y[k * B:(k + 1) * B, 0, :keep]
+        order = sorted(parts)
+        wav = torch.cat([parts[c] for c in order], dim=-1) if len(order) > 1 else parts[order[0]]
         return {"syn_wav_list": [wav[i, : n[i] * self.decoder_upsample_rate] for i in range(B)]}
 
     @torch.inference_mode()

@@ -340,22 +340,36 @@ __device__ __forceinline__ float ordered_f32(int i) {
     return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff);
 }
 
-__global__ void mel_logmax_kernel(float* __restrict__ mel, long ld, int* __restrict__ umax_ord, int T,
-                                  int n_mel) {
-    // grid (ceil(T*n_mel/256), B)
+constexpr int LM_PER_THREAD = 16;
+__global__ __launch_bounds__(256) void mel_logmax_kernel(float* __restrict__ mel, long ld, int* __restrict__ umax_ord,
+                                                         int T, int n_mel) {
+    // grid (ceil(T*n_mel / (256*16)), B): 4096 elements per workgroup, ONE atomic per workgroup
+    // (every wave hammering one address per utterance ran 14x slower than the stream itself)
+    __shared__ float wmax[4];
     const int b = blockIdx.y;
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)T * n_mel;
+    const long base = (long)blockIdx.x * (256 * LM_PER_THREAD) + threadIdx.x;
     float v = -INFINITY;
-    if (i < (long)T * n_mel) {
-        const long t = i / n_mel;
-        const int m = (int)(i - t * n_mel);
-        float* p = mel + ((long)b * T + t) * ld + m;
-        v = log10f(fmaxf(*p, 1e-10f));
-        *p = v;
+#pragma unroll
+    for (int k = 0; k < LM_PER_THREAD; ++k) {
+        const long i = base + 256L * k;
+        if (i < total) {
+            const long t = i / n_mel;
+            const int m = (int)(i - t * n_mel);
+            float* p = mel + ((long)b * T + t) * ld + m;
+            const float x = log10f(fmaxf(*p, 1e-10f));
+            *p = x;
+            v = fmaxf(v, x);
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0 && v > -INFINITY) atomicMax(umax_ord + b, f32_ordered(v));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        v = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (v > -INFINITY) atomicMax(umax_ord + b, f32_ordered(v));
+    }
 }
 
 __global__ void ordered_init_kernel(const float* __restrict__ src, int* __restrict__ dst, int n) {
@@ -594,7 +608,7 @@ extern "C" int swc_mel_logmax(float* mel, int64_t ld, float* umax, int32_t B, in
     if (B <= 0 || T <= 0) return SWC_OK;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(ordered_init_kernel, dim3(nblk(B, 256)), dim3(256), 0, s, umax, (int*)umax, B);
-    hipLaunchKernelGGL(mel_logmax_kernel, dim3(nblk((long)T * n_mel, 256), B), dim3(256), 0, s, mel, (long)ld,
+    hipLaunchKernelGGL(mel_logmax_kernel, dim3(nblk((long)T * n_mel, 256 * LM_PER_THREAD), B), dim3(256), 0, s, mel, (long)ld,
                        (int*)umax, T, n_mel);
     SWC_CHECK_LAUNCH("swc_mel_logmax");
     return SWC_OK;

@@ -144,3 +144,31 @@ def test_no_cpu_fallback():
     m = AudioCodec(PARAMS["tiny"]())
     with pytest.raises(SwcError):
         m.encode([torch.zeros(2000)], device=torch.device("cpu"))
+
+
+def test_window_batching_is_exact():
+    """>= 3 windows: batching independent 30 s windows into one call must not change a single bit
+    relative to the reference's serial window loop (max_rows_per_call = B)."""
+    from simwhisper_codec_amd import synth
+    m = model("tiny", "mixed")
+    wavs = [synth.synth_audio(16000 * 63 + 321, index=90, kind="speech").to(DEV), synth.synth_audio(16000 * 41, index=91).to(DEV),
+            synth.synth_audio(5000, index=92).to(DEV)]
+    try:
+        m.max_rows_per_call = len(wavs)       # serial: one window per call, as the reference
+        c_ser = m.encode(wavs)["codes_list"]
+        w_ser = m.decode(c_ser)["syn_wav_list"]
+        m.max_rows_per_call = 64              # batched
+        c_bat = m.encode(wavs)["codes_list"]
+        w_bat = m.decode(c_bat)["syn_wav_list"]
+    finally:
+        m.max_rows_per_call = 64
+    assert [c.shape[-1] for c in c_bat] == [(16000 * 63 + 321) // 1280, 16000 * 41 // 1280, 5000 // 1280]
+    for a, b in zip(c_ser, c_bat):
+        assert torch.equal(a, b)
+    for a, b in zip(w_ser, w_bat):
+        assert torch.equal(a, b)
+    # and the oracle agrees on the codes of the long utterances
+    o = oracle("tiny")
+    want = o.encode([w.cpu() for w in wavs], trim=True)["codes_list"]
+    for a, b in zip(c_bat, want):
+        assert torch.equal(a.cpu().long(), b.long())
