@@ -61,205 +61,16 @@ struct GemmP {
     int taps, dil, stride, pad, t_in, t_out;
     int act;
     float alpha, out_scale;
+    int dbg;         // diagnostics only (SWC_GEMM_DBG): 1 = skip LDS-DMA, 2 = skip barriers (wrong results, timing only)
     int kc_per_tap;  // ceil(K / BK)
     int n_tiles_n, n_tiles_m;
 };
 
-template <int MODE, typename OutT, int MT, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p) {
-    constexpr bool BF16 = MODE == SWC_BF16;
-    constexpr bool F16S = MODE == SWC_F16S;
-    constexpr int ES = BF16 ? 2 : 4;    // bytes per LOGICAL element (split-f16 is 2 halves = 4 bytes)
-    constexpr int EPC = 16 / ES;        // logical elements per 16-byte chunk (K-tail predicate only)
-    constexpr int BK = ROW_BYTES / ES;  // logical elements of K per slice
-    constexpr int NT = WAVES_M * WAVES_N * 64;
-    constexpr int BM = WAVES_M * MT * 16;
-    constexpr int BN = WAVES_N * 64;
-    constexpr int RPS = NT / 8;  // rows covered by one staging sweep of the workgroup
-    constexpr int NA = BM / RPS;  // A chunks per thread per slice
-    constexpr int NB = BN / RPS;  // W chunks per thread per slice
-    constexpr int A_BYTES = BM * ROW_BYTES;
-    constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage][A rows | W rows][128 B]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
-
-    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so give each XCD
-    // a contiguous run of tiles (neighbours share the A panel in its L2).  Bijective for any grid size.
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid / p.n_tiles_n;
-    const int tn = bid - tm * p.n_tiles_n;
-    const int bm = tm * BM, bn = tn * BN;
-
-    // ---- per-thread staging geometry
-    const int ld_pos = tid & 7;  // chunk POSITION this lane lands on
-    int a_b[NA], a_t[NA], a_chunk[NA];
-    bool a_rowok[NA];
-    long w_rowoff[NB];
-    int w_chunk[NB];
-    bool w_rowok[NB];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int row = (tid >> 3) + RPS * i;
-        const int r = bm + row;
-        a_rowok[i] = r < p.M;
-        const int rr = a_rowok[i] ? r : 0;
-        a_b[i] = rr / p.t_out;
-        a_t[i] = rr - a_b[i] * p.t_out;
-        a_chunk[i] = ld_pos ^ swz(row);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int row = (tid >> 3) + RPS * i;
-        const int n = bn + row;
-        w_rowok[i] = n < p.N;
-        w_rowoff[i] = (long)(w_rowok[i] ? n : 0) * p.ldw;
-        w_chunk[i] = ld_pos ^ swz(row);
-    }
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
-    // Lanes whose tap / K-chunk is out of range fetch a 16-byte device zero page (LDS-DMA cannot
-    // zero-fill).  Rows beyond M / N are clamped instead (their results are never stored).
-    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    const bool plain = (p.taps == 1) && (p.K % BK == 0) && (p.stride == 1) && (p.pad == 0) && (p.t_in == p.t_out);
-    const char* a_ptr[NA];
-    const char* w_ptr[NB];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int row = (tid >> 3) + RPS * i;
-        int r = bm + row;
-        r = r < p.M ? r : p.M - 1;
-        a_ptr[i] = p.A + ((long)r * p.lda + a_chunk[i] * EPC) * ES;  // plain GEMM: t_in == t_out == M
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int row = (tid >> 3) + RPS * i;
-        int n = bn + row;
-        n = n < p.N ? n : p.N - 1;
-        w_ptr[i] = p.W + ((long)n * p.ldw + w_chunk[i] * EPC) * ES;
-    }
-    auto stage_slice = [&](int kt, int stage) {
-        const unsigned sa = smem_base + stage * STAGE_BYTES + 8 * wave_u * ROW_BYTES;
-        const unsigned sb = sa + A_BYTES;
-        if (plain) {
-            const long koff = (long)kt * ROW_BYTES;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) glds16(a_ptr[i] + koff, sa + RPS * i * ROW_BYTES);
-#pragma unroll
-            for (int i = 0; i < NB; ++i) glds16(w_ptr[i] + koff, sb + RPS * i * ROW_BYTES);
-            return;
-        }
-        const int tap = kt / p.kc_per_tap;
-        const int kc = kt - tap * p.kc_per_tap;
-        const int shift = tap * p.dil - p.pad;
-        const char* zero = reinterpret_cast<const char*>(g_zero16);
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int k0 = kc * BK + a_chunk[i] * EPC;
-            const int ts = a_t[i] * p.stride + shift;
-            const bool ok = a_rowok[i] && k0 < p.K && ts >= 0 && ts < p.t_in;
-            const char* src = p.A + (((long)a_b[i] * p.t_in + (ok ? ts : 0)) * p.lda + (ok ? k0 : 0)) * ES;
-            glds16(ok ? src : zero, sa + RPS * i * ROW_BYTES);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int k0 = kc * BK + w_chunk[i] * EPC;
-            const bool ok = w_rowok[i] && k0 < p.K;
-            const char* src = p.W + (w_rowoff[i] + (long)tap * p.K + (ok ? k0 : 0)) * ES;
-            glds16(ok ? src : zero, sb + RPS * i * ROW_BYTES);
-        }
-    };
-    // the LDS-DMA is invisible to the compiler: order it ourselves
-    auto dma_fence = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-
-    f32x4 acc[MT][4];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nkt = p.taps * p.kc_per_tap;
-    stage_slice(0, 0);
-    dma_fence();
-
-    const int fr = lane & 15, fh = lane >> 4;
-    const int a_row0 = wr * (MT * 16) + fr;
-    const int b_row0 = wc * 64 + 16 * (fr >> 2) + (fr & 3);
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nkt) stage_slice(kt + 1, cur ^ 1);
-        const char* sa = smem + cur * STAGE_BYTES;
-        const char* sb = sa + A_BYTES;
-        uint4 ha[F16S ? MT : 1], hb[F16S ? 4 : 1];
-        (void)ha; (void)hb;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            uint4 fa[MT], fb[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                fb[j] = *reinterpret_cast<const uint4*>(sb + lds_off(b_row0 + 4 * j, fh + 4 * g));
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off(a_row0 + 16 * i, fh + 4 * g));
-            if constexpr (F16S) {
-                // chunk g = 0 holds the hi halves of this 32-element slice, g = 1 the lo halves: keep the hi
-                // fragments and fold the three products in once both are in registers (below)
-                if (g == 0) {
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) ha[i] = fa[i];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) hb[j] = fb[j];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < MT; ++i)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            f32x4 c = acc[i][j];
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&fb[j]),
-                                                                       *reinterpret_cast<f16x8*>(&ha[i]), c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&hb[j]),
-                                                                       *reinterpret_cast<f16x8*>(&fa[i]), c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&hb[j]),
-                                                                       *reinterpret_cast<f16x8*>(&ha[i]), c, 0, 0, 0);
-                            acc[i][j] = c;
-                        }
-                }
-            } else if constexpr (BF16) {
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            *reinterpret_cast<bf16x8*>(&fb[j]), *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) {
-                        const float av = __uint_as_float(reinterpret_cast<const unsigned*>(&fa[i])[e]);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float bv = __uint_as_float(reinterpret_cast<const unsigned*>(&fb[j])[e]);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
-                        }
-                    }
-            }
-        }
-        dma_fence();
-    }
-
+// Epilogue shared by all geometries.  Transposed product: lane (fr, fh) holds, for activation row
+// 16i + fr of its wave's slab, the 16 contiguous output columns 16fh + 4j + e.
+template <typename OutT, int MT>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4], int bm, int bn, int wr, int wc, int fr,
+                                              int fh) {
     // ---- epilogue: lane (fr, fh) holds, for row 16i + fr, columns 16fh + 4j + e of its 64-column slab
     OutT* C = reinterpret_cast<OutT*>(p.C);
     const int col0 = bn + wc * 64 + 16 * fh;
@@ -351,6 +162,216 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     }
 }
 
+template <int MODE, typename OutT, int MT, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p) {
+    constexpr bool BF16 = MODE == SWC_BF16;
+    constexpr bool F16S = MODE == SWC_F16S;
+    constexpr int ES = BF16 ? 2 : 4;    // bytes per LOGICAL element (split-f16 is 2 halves = 4 bytes)
+    constexpr int EPC = 16 / ES;        // logical elements per 16-byte chunk (K-tail predicate only)
+    constexpr int BK = ROW_BYTES / ES;  // logical elements of K per slice
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int BM = WAVES_M * MT * 16;
+    constexpr int BN = WAVES_N * 64;
+    constexpr int RPS = NT / 8;  // rows covered by one staging sweep of the workgroup
+    constexpr int NA = BM / RPS;  // A chunks per thread per slice
+    constexpr int NB = BN / RPS;  // W chunks per thread per slice
+    constexpr int A_BYTES = BM * ROW_BYTES;
+    constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [stage][A rows | W rows][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wr = wave / WAVES_N, wc = wave % WAVES_N;
+
+    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so give each XCD
+    // a contiguous run of tiles (neighbours share the A panel in its L2).  Bijective for any grid size.
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / p.n_tiles_n;
+    const int tn = bid - tm * p.n_tiles_n;
+    const int bm = tm * BM, bn = tn * BN;
+
+    // ---- per-thread staging geometry
+    const int ld_pos = tid & 7;  // chunk POSITION this lane lands on
+    int a_b[NA], a_t[NA], a_chunk[NA];
+    bool a_rowok[NA];
+    long w_rowoff[NB];
+    int w_chunk[NB];
+    bool w_rowok[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (tid >> 3) + RPS * i;
+        const int r = bm + row;
+        a_rowok[i] = r < p.M;
+        const int rr = a_rowok[i] ? r : 0;
+        a_b[i] = rr / p.t_out;
+        a_t[i] = rr - a_b[i] * p.t_out;
+        a_chunk[i] = ld_pos ^ swz(row);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int row = (tid >> 3) + RPS * i;
+        const int n = bn + row;
+        w_rowok[i] = n < p.N;
+        w_rowoff[i] = (long)(w_rowok[i] ? n : 0) * p.ldw;
+        w_chunk[i] = ld_pos ^ swz(row);
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    // Lanes whose tap / K-chunk is out of range fetch a 16-byte device zero page (LDS-DMA cannot
+    // zero-fill).  Rows beyond M / N are clamped instead (their results are never stored).
+    const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
+    const bool plain = (p.taps == 1) && (p.K % BK == 0) && (p.stride == 1) && (p.pad == 0) && (p.t_in == p.t_out);
+    const char* a_ptr[NA];
+    const char* w_ptr[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int row = (tid >> 3) + RPS * i;
+        int r = bm + row;
+        r = r < p.M ? r : p.M - 1;
+        a_ptr[i] = p.A + ((long)r * p.lda + a_chunk[i] * EPC) * ES;  // plain GEMM: t_in == t_out == M
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int row = (tid >> 3) + RPS * i;
+        int n = bn + row;
+        n = n < p.N ? n : p.N - 1;
+        w_ptr[i] = p.W + ((long)n * p.ldw + w_chunk[i] * EPC) * ES;
+    }
+    auto stage_slice = [&](int kt, int stage) {
+        const unsigned sa = smem_base + stage * STAGE_BYTES + 8 * wave_u * ROW_BYTES;
+        const unsigned sb = sa + A_BYTES;
+        if (p.dbg & 1) return;
+        if (plain) {
+            const long koff = (long)kt * ROW_BYTES;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) glds16(a_ptr[i] + koff, sa + RPS * i * ROW_BYTES);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) glds16(w_ptr[i] + koff, sb + RPS * i * ROW_BYTES);
+            return;
+        }
+        const int tap = kt / p.kc_per_tap;
+        const int kc = kt - tap * p.kc_per_tap;
+        const int shift = tap * p.dil - p.pad;
+        const char* zero = reinterpret_cast<const char*>(g_zero16);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int k0 = kc * BK + a_chunk[i] * EPC;
+            const int ts = a_t[i] * p.stride + shift;
+            const bool ok = a_rowok[i] && k0 < p.K && ts >= 0 && ts < p.t_in;
+            const char* src = p.A + (((long)a_b[i] * p.t_in + (ok ? ts : 0)) * p.lda + (ok ? k0 : 0)) * ES;
+            glds16(ok ? src : zero, sa + RPS * i * ROW_BYTES);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int k0 = kc * BK + w_chunk[i] * EPC;
+            const bool ok = w_rowok[i] && k0 < p.K;
+            const char* src = p.W + (w_rowoff[i] + (long)tap * p.K + (ok ? k0 : 0)) * ES;
+            glds16(ok ? src : zero, sb + RPS * i * ROW_BYTES);
+        }
+    };
+    // the LDS-DMA is invisible to the compiler: order it ourselves
+    auto dma_fence = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    f32x4 acc[MT][4];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = p.taps * p.kc_per_tap;
+    const int fr = lane & 15, fh = lane >> 4;
+    const int a_row0 = wr * (MT * 16) + fr;
+    const int b_row0 = wc * 64 + 16 * (fr >> 2) + (fr & 3);
+    auto read_frags = [&](int stage, int g, uint4(&fa)[MT], uint4(&fb)[4]) {
+        const char* sa = smem + stage * STAGE_BYTES;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(sb + lds_off(b_row0 + 4 * j, fh + 4 * g));
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off(a_row0 + 16 * i, fh + 4 * g));
+    };
+    {
+    stage_slice(0, 0);
+    dma_fence();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nkt) stage_slice(kt + 1, cur ^ 1);
+        const char* sa = smem + cur * STAGE_BYTES;
+        const char* sb = sa + A_BYTES;
+        uint4 ha[F16S ? MT : 1], hb[F16S ? 4 : 1];
+        (void)ha; (void)hb;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            uint4 fa[MT], fb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fb[j] = *reinterpret_cast<const uint4*>(sb + lds_off(b_row0 + 4 * j, fh + 4 * g));
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off(a_row0 + 16 * i, fh + 4 * g));
+            if constexpr (F16S) {
+                // chunk g = 0 holds the hi halves of this 32-element slice, g = 1 the lo halves: keep the hi
+                // fragments and fold the three products in once both are in registers (below)
+                if (g == 0) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) ha[i] = fa[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hb[j] = fb[j];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4 c = acc[i][j];
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&fb[j]),
+                                                                       *reinterpret_cast<f16x8*>(&ha[i]), c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&hb[j]),
+                                                                       *reinterpret_cast<f16x8*>(&fa[i]), c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&hb[j]),
+                                                                       *reinterpret_cast<f16x8*>(&ha[i]), c, 0, 0, 0);
+                            acc[i][j] = c;
+                        }
+                }
+            } else if constexpr (BF16) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            *reinterpret_cast<bf16x8*>(&fb[j]), *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        const float av = __uint_as_float(reinterpret_cast<const unsigned*>(&fa[i])[e]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float bv = __uint_as_float(reinterpret_cast<const unsigned*>(&fb[j])[e]);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv, av, acc[i][j], 0, 0, 0);
+                        }
+                    }
+            }
+        }
+        dma_fence();
+    }
+
+    }
+
+    gemm_epilogue<OutT, MT>(p, acc, bm, bn, wr, wc, fr, fh);
+}
+
 template <int MODE, typename OutT, int MT, int WM, int WN>
 int launch(GemmP p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * 64;
@@ -378,6 +399,7 @@ int launch(GemmP p, hipStream_t s) {
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, s, p);
     return SWC_OK;
 }
+
 
 }  // namespace
 
@@ -431,10 +453,15 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     const int bk = bf ? 64 : 32;
     p.kc_per_tap = (a->K + bk - 1) / bk;
     p.n_tiles_n = p.n_tiles_m = 0;
+    {
+        static int dbg = -1;
+        if (dbg < 0) dbg = getenv("SWC_GEMM_DBG") ? atoi(getenv("SWC_GEMM_DBG")) : 0;
+        p.dbg = dbg;
+    }
     hipStream_t s = (hipStream_t)stream;
     // geometry: the 256x256 / 8-wave tile pays off when its grid still fills the 256 CUs
     const long big_tiles = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
-    bool big = bf && a->N >= 256 && big_tiles >= 192;
+    bool big = bf && a->N >= 256 && big_tiles >= 96;
     if (tile_override() == 128) big = false;
     if (tile_override() == 256) big = bf;
     int rc;
