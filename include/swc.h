@@ -204,6 +204,14 @@ int swc_istft_spec(const float* h, int64_t ldh, void* s, int64_t lds, int64_t ro
 int swc_istft_ola(const float* frames, const float* window_sq, float* wav, int32_t B, int32_t T,
                   void* stream);
 
+/*
+ * Code bitstream (the reference keeps codes in memory only, model.py:302): 8 groups x 11 bits
+ * = 11 bytes per 12.5 Hz frame (1100 bit/s).  codes [8][ldg] int32 (row g = group g, values < 2048) <-> bytes [11*T];
+ * frame t = bytes 11t..11t+10, group g = bits 11g..11g+10 of the frame, LSB first.
+ */
+int swc_codes_pack(const int32_t* codes, int64_t ldg, void* bytes, int32_t T, void* stream);
+int swc_codes_unpack(const void* bytes, int32_t* codes, int64_t ldg, int32_t T, void* stream);
+
 /* f32 -> bf16 cast (weight packing / mode switches) */
 int swc_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
 /* f32 [rows][ldx] (first K columns) -> split-f16 [rows][K] logical (K % 32 == 0), x scaled by `scale` */

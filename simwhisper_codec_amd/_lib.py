@@ -55,6 +55,8 @@ SIGNATURES = {
     "swc_deconv_col2im": [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
     "swc_istft_spec": [_P, _L, _P, _L, _L, _I, _P],
     "swc_istft_ola": [_P, _P, _P, _I, _I, _P],
+    "swc_codes_pack": [_P, _L, _P, _I, _P],
+    "swc_codes_unpack": [_P, _P, _L, _I, _P],
     "swc_cast_f32_bf16": [_P, _P, _L, _P],
     "swc_cast_f32_f16s": [_P, _L, _P, _L, _I, _F, _P],
 }

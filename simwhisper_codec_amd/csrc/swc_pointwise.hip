@@ -690,3 +690,64 @@ extern "C" int swc_cast_f32_bf16(const float* x, void* y, int64_t n, void* strea
     SWC_CHECK_LAUNCH("swc_cast_f32_bf16");
     return SWC_OK;
 }
+
+// ---------------------------------------------------------------- code bitstream
+// 8 groups x 11 bits (2016 < 2^11 codes per group) = 88 bits = 11 bytes per 12.5 Hz frame: 1100 bit/s, the
+// codec's nominal bitrate.  Frame t occupies bytes [11 t, 11 t + 11); group g occupies bits [11 g, 11 g + 11) of
+// the frame, least-significant bit first.  The reference keeps codes in memory only (model.py:302).
+namespace {
+__global__ void codes_pack_kernel(const int* __restrict__ codes, long ldg, unsigned char* __restrict__ out, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    unsigned long long lo = 0;  // bits 0..63
+    unsigned int hi = 0;        // bits 64..87
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const unsigned long long c = (unsigned)codes[g * ldg + t] & 0x7ffu;
+        const int sh = 11 * g;
+        if (sh < 64) lo |= c << sh;
+        if (sh + 11 > 64) hi |= (unsigned)(sh >= 64 ? c << (sh - 64) : c >> (64 - sh));
+    }
+    unsigned char* p = out + 11L * t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = (unsigned char)(lo >> (8 * i));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p[8 + i] = (unsigned char)(hi >> (8 * i));
+}
+__global__ void codes_unpack_kernel(const unsigned char* __restrict__ in, int* __restrict__ codes, long ldg, int T) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const unsigned char* p = in + 11L * t;
+    unsigned long long lo = 0;
+    unsigned int hi = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lo |= (unsigned long long)p[i] << (8 * i);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) hi |= (unsigned)p[8 + i] << (8 * i);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int sh = 11 * g;
+        unsigned long long v = sh < 64 ? lo >> sh : 0;
+        if (sh + 11 > 64) v |= sh >= 64 ? (unsigned long long)(hi >> (sh - 64)) : (unsigned long long)hi << (64 - sh);
+        codes[g * ldg + t] = (int)(v & 0x7ffu);
+    }
+}
+}  // namespace
+
+extern "C" int swc_codes_pack(const int32_t* codes, int64_t ldg, void* bytes, int32_t T, void* stream) {
+    if (T == 0) return SWC_OK;
+    SWC_CHECK_ARG(codes && bytes && ldg >= T && T > 0, "swc_codes_pack: bad args");
+    hipLaunchKernelGGL(codes_pack_kernel, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream, codes, (long)ldg,
+                       (unsigned char*)bytes, T);
+    SWC_CHECK_LAUNCH("swc_codes_pack");
+    return SWC_OK;
+}
+
+extern "C" int swc_codes_unpack(const void* bytes, int32_t* codes, int64_t ldg, int32_t T, void* stream) {
+    if (T == 0) return SWC_OK;
+    SWC_CHECK_ARG(codes && bytes && ldg >= T && T > 0, "swc_codes_unpack: bad args");
+    hipLaunchKernelGGL(codes_unpack_kernel, dim3((T + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)bytes, codes, (long)ldg, T);
+    SWC_CHECK_LAUNCH("swc_codes_unpack");
+    return SWC_OK;
+}

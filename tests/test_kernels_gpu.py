@@ -2,6 +2,7 @@
 fp32/fp64 statement of the same op (run on the host CPU), called through the C-ABI."""
 import math
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -487,3 +488,23 @@ def test_attention16_spike():
     q, k, v = [t.double() for t in qkv[0].chunk(3, dim=-1)]
     ref = torch.softmax(q @ k.T, -1) @ v
     assert (out - ref).abs().max().item() < 1e-5
+
+
+def test_code_bitstream(tmp_path):
+    from simwhisper_codec_amd import bitstream
+    from oracle import bitstream_np
+    g = torch.Generator().manual_seed(4)
+    for T in (0, 1, 7, 1000):
+        codes = torch.randint(0, 2016, (8, T), generator=g, dtype=torch.int32)
+        if T:
+            codes[:, 0] = torch.tensor([0, 2015, 1, 1024, 2047 & 2015, 7, 2015, 0])
+        payload = bitstream.pack_codes(codes.to(DEV))
+        assert payload.numel() == 11 * T
+        assert np.array_equal(payload.cpu().numpy(), bitstream_np.pack(codes.numpy()))
+        back = bitstream.unpack_codes(payload, T)
+        assert torch.equal(back.cpu(), codes)
+        assert np.array_equal(bitstream_np.unpack(payload.cpu().numpy(), T), codes.numpy())
+    p = tmp_path / "x.swc"
+    bitstream.write_codes(str(p), codes.to(DEV))
+    assert p.stat().st_size == 12 + 11 * 1000  # 1100 bit/s + 12-byte header
+    assert torch.equal(bitstream.read_codes(str(p)).cpu(), codes)
