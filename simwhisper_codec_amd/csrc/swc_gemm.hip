@@ -23,7 +23,6 @@
 
 namespace {
 
-constexpr int ROW_BYTES = 128;  // bytes of K per LDS row per slice
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
@@ -47,7 +46,12 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 // conflict-free for the four 16-lane groups of ds_read_b128, both for 16 consecutive rows (activation
 // fragments) and for the permuted weight rows {16a + 4j + b} (checked exhaustively)
 __device__ __forceinline__ int swz(int row) { return ((row >> 1) ^ ((row >> 4) << 1)) & 7; }
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ swz(row)) << 4); }
+// 64-byte rows: conflict-free for both patterns as well (checked exhaustively)
+__device__ __forceinline__ int swz64(int row) { return ((-(row >> 2)) ^ (-(row >> 4))) & 3; }
+template <int RB>
+__device__ __forceinline__ int swz_rb(int row) { return RB == 128 ? swz(row) : swz64(row); }
+template <int RB>
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * RB + ((chunk ^ swz_rb<RB>(row)) << 4); }
 
 struct GemmP {
     const char* A;
@@ -162,8 +166,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
     }
 }
 
-template <int MODE, typename OutT, int MT, int WAVES_M, int WAVES_N>
+template <int MODE, typename OutT, int MT, int WAVES_M, int WAVES_N, int RB = 128>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p) {
+    constexpr int ROW_BYTES = RB;  // bytes of K per LDS row per slice: 128, or 64 (bf16 / f32 only: smaller stages, two workgroups per CU)
+    constexpr int CPR = RB / 16;   // 16-byte chunks per row
+    constexpr int NG = RB / 64;    // 64-byte k-groups per slice
+    static_assert(RB == 128 || (RB == 64 && MODE != SWC_F16S), "split-f16 needs hi|lo in one 128-byte row");
     constexpr bool BF16 = MODE == SWC_BF16;
     constexpr bool F16S = MODE == SWC_F16S;
     constexpr int ES = BF16 ? 2 : 4;    // bytes per LOGICAL element (split-f16 is 2 halves = 4 bytes)
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     constexpr int NT = WAVES_M * WAVES_N * 64;
     constexpr int BM = WAVES_M * MT * 16;
     constexpr int BN = WAVES_N * 64;
-    constexpr int RPS = NT / 8;  // rows covered by one staging sweep of the workgroup
+    constexpr int RPS = NT / CPR;  // rows covered by one staging sweep of the workgroup
     constexpr int NA = BM / RPS;  // A chunks per thread per slice
     constexpr int NB = BN / RPS;  // W chunks per thread per slice
     constexpr int A_BYTES = BM * ROW_BYTES;
@@ -198,7 +206,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     const int bm = tm * BM, bn = tn * BN;
 
     // ---- per-thread staging geometry
-    const int ld_pos = tid & 7;  // chunk POSITION this lane lands on
+    const int ld_pos = tid % CPR;  // chunk POSITION this lane lands on
+    const int ld_row = tid / CPR;  // row inside one staging sweep
     int a_b[NA], a_t[NA], a_chunk[NA];
     bool a_rowok[NA];
     long w_rowoff[NB];
@@ -206,21 +215,21 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     bool w_rowok[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int row = (tid >> 3) + RPS * i;
+        const int row = ld_row + RPS * i;
         const int r = bm + row;
         a_rowok[i] = r < p.M;
         const int rr = a_rowok[i] ? r : 0;
         a_b[i] = rr / p.t_out;
         a_t[i] = rr - a_b[i] * p.t_out;
-        a_chunk[i] = ld_pos ^ swz(row);
+        a_chunk[i] = ld_pos ^ swz_rb<RB>(row);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int row = (tid >> 3) + RPS * i;
+        const int row = ld_row + RPS * i;
         const int n = bn + row;
         w_rowok[i] = n < p.N;
         w_rowoff[i] = (long)(w_rowok[i] ? n : 0) * p.ldw;
-        w_chunk[i] = ld_pos ^ swz(row);
+        w_chunk[i] = ld_pos ^ swz_rb<RB>(row);
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
@@ -232,20 +241,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     const char* w_ptr[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int row = (tid >> 3) + RPS * i;
+        const int row = ld_row + RPS * i;
         int r = bm + row;
         r = r < p.M ? r : p.M - 1;
         a_ptr[i] = p.A + ((long)r * p.lda + a_chunk[i] * EPC) * ES;  // plain GEMM: t_in == t_out == M
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-        const int row = (tid >> 3) + RPS * i;
+        const int row = ld_row + RPS * i;
         int n = bn + row;
         n = n < p.N ? n : p.N - 1;
         w_ptr[i] = p.W + ((long)n * p.ldw + w_chunk[i] * EPC) * ES;
     }
     auto stage_slice = [&](int kt, int stage) {
-        const unsigned sa = smem_base + stage * STAGE_BYTES + 8 * wave_u * ROW_BYTES;
+        const unsigned sa = smem_base + stage * STAGE_BYTES + wave_u * 1024;  // one wave-instruction = 1 KiB of rows
         const unsigned sb = sa + A_BYTES;
         if (p.dbg & 1) return;
         if (plain) {
@@ -296,9 +305,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         const char* sa = smem + stage * STAGE_BYTES;
         const char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(sb + lds_off(b_row0 + 4 * j, fh + 4 * g));
+        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(sb + lds_off<RB>(b_row0 + 4 * j, fh + 4 * g));
 #pragma unroll
-        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off(a_row0 + 16 * i, fh + 4 * g));
+        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off<RB>(a_row0 + 16 * i, fh + 4 * g));
     };
     {
     stage_slice(0, 0);
@@ -312,14 +321,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         uint4 ha[F16S ? MT : 1], hb[F16S ? 4 : 1];
         (void)ha; (void)hb;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
+        for (int g = 0; g < NG; ++g) {
             uint4 fa[MT], fb[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                fb[j] = *reinterpret_cast<const uint4*>(sb + lds_off(b_row0 + 4 * j, fh + 4 * g));
+                fb[j] = *reinterpret_cast<const uint4*>(sb + lds_off<RB>(b_row0 + 4 * j, fh + 4 * g));
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off(a_row0 + 16 * i, fh + 4 * g));
+                fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off<RB>(a_row0 + 16 * i, fh + 4 * g));
             if constexpr (F16S) {
                 // chunk g = 0 holds the hi halves of this 32-element slice, g = 1 the lo halves: keep the hi
                 // fragments and fold the three products in once both are in registers (below)
@@ -372,10 +381,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     gemm_epilogue<OutT, MT>(p, acc, bm, bn, wr, wc, fr, fh);
 }
 
-template <int MODE, typename OutT, int MT, int WM, int WN>
+template <int MODE, typename OutT, int MT, int WM, int WN, int RB = 128>
 int launch(GemmP p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * 64;
-    constexpr int LDS = 2 * (BM + BN) * ROW_BYTES;
+    constexpr int LDS = 2 * (BM + BN) * RB;
+    {
+        constexpr int BK = RB / (MODE == SWC_BF16 ? 2 : 4);
+        p.kc_per_tap = (p.K + BK - 1) / BK;
+    }
     p.n_tiles_n = (p.N + BN - 1) / BN;
     p.n_tiles_m = (p.M + BM - 1) / BM;
     const long nwg = (long)p.n_tiles_n * p.n_tiles_m;
@@ -383,7 +396,7 @@ int launch(GemmP p, hipStream_t s) {
         swc_set_error("swc_gemm: grid too large");
         return SWC_E_ARG;
     }
-    auto kern = gemm_kernel<MODE, OutT, MT, WM, WN>;
+    auto kern = gemm_kernel<MODE, OutT, MT, WM, WN, RB>;
     if (LDS > 64 * 1024) {
         static bool attr_set = false;  // per instantiation; benign race (same value)
         if (!attr_set) {
