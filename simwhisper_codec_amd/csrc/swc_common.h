@@ -83,4 +83,18 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return fmaf(-x, r, x);
 }
 
+// GELU for split-f16 outputs (f32-class path): erf by Abramowitz-Stegun 7.1.26, |erf error| <= 1.5e-7 (the size of
+// an f32 rounding of a value near 1), branch-free, ~17 VALU + 2 transcendental ops instead of libm's erff.
+__device__ __forceinline__ float gelu_as(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __expf(-z * z);
+    const float erf_abs = 1.0f - poly * t * e;
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -98,7 +98,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = acc[i][j][e] * p.alpha + bv[4 * j + e];
-                if (p.act == SWC_ACT_GELU) x = __is_same(OutT, bf16_t) ? gelu_fast(x) : gelu_erf(x);
+                if (p.act == SWC_ACT_GELU) x = __is_same(OutT, bf16_t) ? gelu_fast(x) : (__is_same(OutT, f16s_t) ? gelu_as(x) : gelu_erf(x));
                 v[4 * j + e] = x * gv[4 * j + e];
             }
         if constexpr (sizeof(OutT) == sizeof(f16s_t) && !__is_same(OutT, bf16_t)) {
