@@ -60,6 +60,17 @@ class GemmTimer:
         return out
 
 
+def pmc_traffic(kind):
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 --pmc passes
+    (profiles/r01_pmc_gemm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes of this
+    same command).  PMC cannot be collected from inside the timed run, so this is the profiled value, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")) as f:
+            return round(json.load(f)[kind]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(gp, sd, n_utt, seconds, threads):
     from oracle.ref_cpu import Oracle
     from simwhisper_codec_amd import synth
@@ -161,7 +172,7 @@ def main():
                 line["roofline"] = {
                     "bound": "mfma", "kernel": f"swc_gemm ({kind})", "achieved": round(ach, 2),
                     "peak": round(PEAK_TFLOPS[kind], 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[kind], 4),
-                    "traffic": None,
+                    "traffic": pmc_traffic(kind),
                     "launches_per_step": d["launches"] // args.steps,
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4),
                     "share_of_step": round(d["ms"] / (1e3 * elapsed), 3),
