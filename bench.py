@@ -152,7 +152,7 @@ def main():
     if rank == 0:
         audio_s = world * args.batch * args.seconds * args.steps
         line = {
-            "metric": "audio-sec/sec encode+decode (RTF^-1), 16kHz batch=32x10s",
+            "metric": f"audio-sec/sec encode+decode (RTF^-1), 16kHz batch={args.batch}x{args.seconds:g}s",
             "value": round(audio_s / elapsed, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,

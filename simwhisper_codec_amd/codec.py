@@ -143,7 +143,11 @@ class AudioCodec(nn.Module):
         with open(config_path, "r") as f:
             config = yaml.safe_load(f)
         model = cls(config["generator_params"])
-        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+        if str(ckpt_path).endswith(".safetensors"):  # tools/pack_checkpoint.py output: same keys, no pickle
+            from safetensors.torch import load_file
+            ckpt = load_file(ckpt_path, device="cpu")
+        else:
+            ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
         model.load_state_dict(ckpt["model"] if "model" in ckpt else ckpt, strict=True)
         return model
 

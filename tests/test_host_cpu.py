@@ -125,6 +125,26 @@ def test_model_surface_and_checkpoint_roundtrip(tmp_path):
     assert m.encode([], device=torch.device("cpu")) == {"codes_list": []}
 
 
+def test_pack_checkpoint_tool(tmp_path):
+    import subprocess, sys, yaml
+    from audiocodec.model import AudioCodec
+    gp = PARAMS["tiny"]()
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(yaml.safe_dump({"generator_params": gp}))
+    sd = state_dict("tiny")
+    torch.save({"model": sd}, tmp_path / "m.pt")
+    out = tmp_path / "m.safetensors"
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pack_checkpoint.py"), "--config", str(cfg), "--in",
+                    str(tmp_path / "m.pt"), "--out", str(out)], check=True, capture_output=True)
+    got = AudioCodec.load_from_checkpoint(str(cfg), str(out)).state_dict()
+    assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd)
+    bad = dict(sd); bad.pop("vocos.head.out.bias")
+    torch.save(bad, tmp_path / "bad.pt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pack_checkpoint.py"), "--config", str(cfg), "--in",
+                        str(tmp_path / "bad.pt"), "--out", str(tmp_path / "x.safetensors")], capture_output=True)
+    assert r.returncode != 0 and b"key mismatch" in r.stderr
+
+
 def test_wav_io_roundtrip(tmp_path):
     import struct
     from simwhisper_codec_amd.wavio import find_audio_files, load_audio, save_audio
