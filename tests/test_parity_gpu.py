@@ -172,3 +172,53 @@ def test_window_batching_is_exact():
     want = o.encode([w.cpu() for w in wavs], trim=True)["codes_list"]
     for a, b in zip(c_bat, want):
         assert torch.equal(a.cpu().long(), b.long())
+
+
+def test_api_edge_cases():
+    """inputs on the host, empty members, single utterance, float64 audio: same answers as the oracle."""
+    from simwhisper_codec_amd import synth
+    m = model("tiny", "mixed")
+    o = oracle("tiny")
+    wavs = [synth.synth_audio(9000, index=70, kind="speech"), torch.zeros(0), synth.synth_audio(2560, index=71).double()]
+    got = m.encode(wavs)["codes_list"]                      # CPU inputs, default device
+    want = o.encode([w.float() for w in wavs], trim=True)["codes_list"]
+    assert [tuple(c.shape) for c in got] == [(8, 7), (8, 0), (8, 2)]
+    for a, b in zip(got, want):
+        assert a.is_cuda and torch.equal(a.cpu().long(), b.long())
+    dec = m.decode([c.cpu().long() for c in got])["syn_wav_list"]   # CPU int64 codes in
+    ref = o.decode(want)["syn_wav_list"]
+    assert [w.shape[0] for w in dec] == [7 * 1280, 0, 2 * 1280]
+    for a, b in zip(dec, ref):
+        if b.numel():
+            assert _relerr(a.cpu().numpy(), b.numpy()) < TOL_BF16
+    one = m.encode([wavs[0].to(DEV)])["codes_list"]
+    assert torch.equal(one[0], got[0])                      # batch-size independence of encode
+    assert m.encode([])["codes_list"] == [] and m.decode([])["syn_wav_list"] == []
+    assert m.decode([torch.zeros(8, 0, dtype=torch.long)])["syn_wav_list"][0].numel() == 0
+
+
+def test_cli_end_to_end(tmp_path):
+    """inference.py flags, file naming and PCM16 output on a tiny config with the synthetic checkpoint."""
+    import yaml
+    import inference
+    from simwhisper_codec_amd import synth
+    from simwhisper_codec_amd.wavio import load_audio, save_audio
+    cfg = tmp_path / "tiny.yaml"
+    cfg.write_text(yaml.safe_dump({"generator_params": PARAMS["tiny"]()}))
+    ind, outd = tmp_path / "in" / "sub", tmp_path / "out"
+    ind.mkdir(parents=True)
+    lens = {"a.wav": 16000, "b.wav": 5000, "c.wav": 40000}
+    for i, (name, n) in enumerate(lens.items()):
+        save_audio(str(ind / name), synth.synth_audio(n, index=80 + i, kind="speech").reshape(1, -1), 16000)
+    inference.main(["--config_path", str(cfg), "--synthetic_checkpoint", "--device", "cuda", "--batch_size", "2",
+                    "--input_dir", str(tmp_path / "in"), "--output_dir", str(outd), "--precision", "mixed"])
+    m = model("tiny", "mixed")
+    for name, n in lens.items():
+        y = load_audio(str(outd / name), 16000).reshape(-1)
+        assert y.shape[0] == (n // 1280) * 1280
+    # batch of the first two files (sorted order a, b) reproduces the CLI's first batch exactly up to PCM16 rounding
+    wavs = [load_audio(str(ind / k), 16000).reshape(-1).to(DEV) for k in ("a.wav", "b.wav")]
+    ref = m.decode(m.encode(wavs)["codes_list"])["syn_wav_list"]
+    for k, r in zip(("a.wav", "b.wav"), ref):
+        y = load_audio(str(outd / k), 16000).reshape(-1)
+        assert (y - r.cpu().clamp(-1, 1)).abs().max().item() <= 1.0 / 32767 + 1e-6
