@@ -65,6 +65,7 @@ struct GemmP {
     int taps, dil, stride, pad, t_in, t_out;
     int act;
     float alpha, out_scale;
+    int band;        // tile-order band height (row panels), see the kernel
     int dbg;         // diagnostics only (SWC_GEMM_DBG): 1 = skip LDS-DMA, 2 = skip barriers (wrong results, timing only)
     int kc_per_tap;  // ceil(K / BK)
     int n_tiles_n, n_tiles_m;
@@ -201,8 +202,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / p.n_tiles_n;
-    const int tn = bid - tm * p.n_tiles_n;
+    // tiles are walked in bands of p.band row panels, column-major inside a band: with band = 4 the ~32 tiles an XCD
+    // runs at the same time form a 4 x 8 block (12 distinct operand panels per K step instead of 18 for a 2 x 16
+    // strip: +9 % at 32768 x 4096 x 4096); narrow outputs (few column tiles) keep band = 1 (row-major)
+    const int BAND = p.band;
+    const int band = bid / (BAND * p.n_tiles_n);
+    const int rem = bid - band * (BAND * p.n_tiles_n);
+    const int rows_in_band = (p.n_tiles_m - band * BAND) < BAND ? (p.n_tiles_m - band * BAND) : BAND;
+    const int tn = rem / rows_in_band;
+    const int tm = band * BAND + (rem - tn * rows_in_band);
     const int bm = tm * BM, bn = tn * BN;
 
     // ---- per-thread staging geometry
@@ -391,6 +399,11 @@ int launch(GemmP p, hipStream_t s) {
     }
     p.n_tiles_n = (p.N + BN - 1) / BN;
     p.n_tiles_m = (p.M + BM - 1) / BM;
+    {
+        static int forced = -1;
+        if (forced < 0) forced = getenv("SWC_GEMM_BAND") ? atoi(getenv("SWC_GEMM_BAND")) : 0;
+        p.band = forced > 0 ? forced : (p.n_tiles_n >= 12 ? 4 : 1);
+    }
     const long nwg = (long)p.n_tiles_n * p.n_tiles_m;
     if (nwg >= (1L << 30)) {
         swc_set_error("swc_gemm: grid too large");
