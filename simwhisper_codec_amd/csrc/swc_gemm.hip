@@ -495,13 +495,35 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
 #define SWC_LAUNCH(MODE, MT, WM, WN)                                                        \
     (cd == SWC_BF16 ? launch<MODE, bf16_t, MT, WM, WN>(p, s)                                 \
                     : (cd == SWC_F16S ? launch<MODE, f16s_t, MT, WM, WN>(p, s) : launch<MODE, float, MT, WM, WN>(p, s)))
+    // 8-wave geometries differ only in the rows per tile (256 / 192 / 128 x 256 columns): pick the one whose grid
+    // quantises best over the 256 CUs.  cost ~ rounds x (rows + fixed per-tile overhead); e.g. M = 16000, N = 768:
+    // 189 tiles of 256 rows leave a quarter of the chip idle, 252 tiles of 192 rows fill it in one round.
+    int mt = 8;
+    if ((bf && big) || (fs && a->N >= 256 && big_tiles >= 96)) {
+        static int forced = -1;
+        if (forced < 0) forced = getenv("SWC_GEMM_MT") ? atoi(getenv("SWC_GEMM_MT")) : 0;
+        const long ntn = (a->N + 255) / 256;
+        double best = 1e30;
+        for (int cand : {8, 6, 4}) {
+            const long tiles = ((a->M + cand * 32 - 1) / (cand * 32)) * ntn;
+            const double cost = (double)((tiles + 255) / 256) * (cand + 1.5);
+            if (cost < best - 1e-9) { best = cost; mt = cand; }
+        }
+        if (forced == 8 || forced == 6 || forced == 4) mt = forced;
+    }
     if (bf) {
-        rc = big ? SWC_LAUNCH(SWC_BF16, 8, 2, 4) : SWC_LAUNCH(SWC_BF16, 4, 2, 2);
+        if (big)
+            rc = mt == 8 ? SWC_LAUNCH(SWC_BF16, 8, 2, 4) : (mt == 6 ? SWC_LAUNCH(SWC_BF16, 6, 2, 4) : SWC_LAUNCH(SWC_BF16, 4, 2, 4));
+        else
+            rc = SWC_LAUNCH(SWC_BF16, 4, 2, 2);
     } else if (fs) {
         bool bigs = a->N >= 256 && big_tiles >= 96;
         if (tile_override() == 128) bigs = false;
         if (tile_override() == 256) bigs = true;
-        rc = bigs ? SWC_LAUNCH(SWC_F16S, 8, 2, 4) : SWC_LAUNCH(SWC_F16S, 4, 2, 2);
+        if (bigs)
+            rc = mt == 8 ? SWC_LAUNCH(SWC_F16S, 8, 2, 4) : (mt == 6 ? SWC_LAUNCH(SWC_F16S, 6, 2, 4) : SWC_LAUNCH(SWC_F16S, 4, 2, 4));
+        else
+            rc = SWC_LAUNCH(SWC_F16S, 4, 2, 2);
     } else {
         rc = SWC_LAUNCH(SWC_F32, 4, 2, 2);
     }
