@@ -194,26 +194,34 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     const int wave = tid >> 6;
     const int wr = wave / WAVES_N, wc = wave % WAVES_N;
 
-    // XCD-aware tile order: workgroups b and b+8 share an XCD (round-robin dispatch), so give each XCD
-    // a contiguous run of tiles (neighbours share the A panel in its L2).  Bijective for any grid size.
-    const int nwg = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    // XCD-aware, persistent tile walk: workgroups b and b+8 share an XCD (round-robin dispatch), so every XCD owns
+    // a contiguous chunk of the tile sequence (neighbours share operand panels in its L2) and its workgroups stride
+    // through that chunk.  With gridDim == number of tiles every workgroup gets exactly one tile.
+    const int ntiles = p.n_tiles_m * p.n_tiles_n;
+    const int xcd = blockIdx.x & 7;
+    const int gw = ((int)gridDim.x - xcd + 7) >> 3;  // workgroups on this XCD
+    const int cq = ntiles >> 3, cr = ntiles & 7;
+    const int chunk_start = xcd < cr ? xcd * (cq + 1) : cr * (cq + 1) + (xcd - cr) * cq;
+    const int chunk_size = cq + (xcd < cr ? 1 : 0);
+    int tl = blockIdx.x >> 3;  // local tile index inside the chunk
+    if (tl >= chunk_size) return;
+    int bm, bn;
     // tiles are walked in bands of p.band row panels, column-major inside a band: with band = 4 the ~32 tiles an XCD
     // runs at the same time form a 4 x 8 block (12 distinct operand panels per K step instead of 18 for a 2 x 16
     // strip: +9 % at 32768 x 4096 x 4096); narrow outputs (few column tiles) keep band = 1 (row-major)
-    const int BAND = p.band;
-    const int band = bid / (BAND * p.n_tiles_n);
-    const int rem = bid - band * (BAND * p.n_tiles_n);
-    const int rows_in_band = (p.n_tiles_m - band * BAND) < BAND ? (p.n_tiles_m - band * BAND) : BAND;
-    const int tn = rem / rows_in_band;
-    const int tm = band * BAND + (rem - tn * rows_in_band);
-    const int bm = tm * BM, bn = tn * BN;
+    auto tile_origin = [&](int local) {
+        const int bid = chunk_start + local;
+        const int BAND = p.band;
+        const int band = bid / (BAND * p.n_tiles_n);
+        const int rem = bid - band * (BAND * p.n_tiles_n);
+        const int rows_in_band = (p.n_tiles_m - band * BAND) < BAND ? (p.n_tiles_m - band * BAND) : BAND;
+        const int tn = rem / rows_in_band;
+        const int tm = band * BAND + (rem - tn * rows_in_band);
+        bm = tm * BM;
+        bn = tn * BN;
+    };
 
-    // ---- per-thread staging geometry
+    // ---- per-thread staging geometry (per tile: setup_tile)
     const int ld_pos = tid % CPR;  // chunk POSITION this lane lands on
     const int ld_row = tid / CPR;  // row inside one staging sweep
     int a_b[NA], a_t[NA], a_chunk[NA];
@@ -221,46 +229,39 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     long w_rowoff[NB];
     int w_chunk[NB];
     bool w_rowok[NB];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int row = ld_row + RPS * i;
-        const int r = bm + row;
-        a_rowok[i] = r < p.M;
-        const int rr = a_rowok[i] ? r : 0;
-        a_b[i] = rr / p.t_out;
-        a_t[i] = rr - a_b[i] * p.t_out;
-        a_chunk[i] = ld_pos ^ swz_rb<RB>(row);
-    }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int row = ld_row + RPS * i;
-        const int n = bn + row;
-        w_rowok[i] = n < p.N;
-        w_rowoff[i] = (long)(w_rowok[i] ? n : 0) * p.ldw;
-        w_chunk[i] = ld_pos ^ swz_rb<RB>(row);
-    }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-
     // Lanes whose tap / K-chunk is out of range fetch a 16-byte device zero page (LDS-DMA cannot
     // zero-fill).  Rows beyond M / N are clamped instead (their results are never stored).
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
     const bool plain = (p.taps == 1) && (p.K % BK == 0) && (p.stride == 1) && (p.pad == 0) && (p.t_in == p.t_out);
     const char* a_ptr[NA];
     const char* w_ptr[NB];
+    auto setup_tile = [&](int local) {
+        tile_origin(local);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int row = ld_row + RPS * i;
-        int r = bm + row;
-        r = r < p.M ? r : p.M - 1;
-        a_ptr[i] = p.A + ((long)r * p.lda + a_chunk[i] * EPC) * ES;  // plain GEMM: t_in == t_out == M
-    }
+        for (int i = 0; i < NA; ++i) {
+            const int row = ld_row + RPS * i;
+            const int r = bm + row;
+            a_rowok[i] = r < p.M;
+            const int rr = a_rowok[i] ? r : 0;
+            a_b[i] = rr / p.t_out;
+            a_t[i] = rr - a_b[i] * p.t_out;
+            a_chunk[i] = ld_pos ^ swz_rb<RB>(row);
+            const int rc = r < p.M ? r : p.M - 1;
+            a_ptr[i] = p.A + ((long)rc * p.lda + a_chunk[i] * EPC) * ES;  // plain GEMM: t_in == t_out == M
+        }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int row = ld_row + RPS * i;
-        int n = bn + row;
-        n = n < p.N ? n : p.N - 1;
-        w_ptr[i] = p.W + ((long)n * p.ldw + w_chunk[i] * EPC) * ES;
-    }
+        for (int i = 0; i < NB; ++i) {
+            const int row = ld_row + RPS * i;
+            const int n = bn + row;
+            w_rowok[i] = n < p.N;
+            w_rowoff[i] = (long)(w_rowok[i] ? n : 0) * p.ldw;
+            w_chunk[i] = ld_pos ^ swz_rb<RB>(row);
+            const int nc = n < p.N ? n : p.N - 1;
+            w_ptr[i] = p.W + ((long)nc * p.ldw + w_chunk[i] * EPC) * ES;
+        }
+    };
+    setup_tile(tl);
     auto stage_slice = [&](int kt, int stage) {
         const unsigned sa = smem_base + stage * STAGE_BYTES + wave_u * 1024;  // one wave-instruction = 1 KiB of rows
         const unsigned sb = sa + A_BYTES;
@@ -317,10 +318,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off<RB>(a_row0 + 16 * i, fh + 4 * g));
     };
-    {
     stage_slice(0, 0);
     dma_fence();
-
+    for (;;) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) stage_slice(kt + 1, cur ^ 1);
@@ -383,10 +383,24 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         }
         dma_fence();
     }
-
+    // Persistent walk: the first K slice of this workgroup's next tile is put in flight before the epilogue, so
+    // its latency (and the next workgroup launch) hides under the GELU / store tail.  Stage 0 is free: every
+    // wave passed the fence that closed the last slice.
+    const int bm_done = bm, bn_done = bn;
+    tl += gw;
+    const bool more = tl < chunk_size;
+    if (more) {
+        setup_tile(tl);
+        stage_slice(0, 0);
     }
-
-    gemm_epilogue<OutT, MT>(p, acc, bm, bn, wr, wc, fr, fh);
+    gemm_epilogue<OutT, MT>(p, acc, bm_done, bn_done, wr, wc, fr, fh);
+    if (!more) break;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dma_fence();
+    }
 }
 
 template <int MODE, typename OutT, int MT, int WM, int WN, int RB = 128>
@@ -422,7 +436,12 @@ int launch(GemmP p, hipStream_t s) {
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WM * WN * 64), LDS, s, p);
+    // persistent grid: one workgroup per CU for the 8-wave geometries, two for the 4-wave one (256 CUs)
+    static int persist = -1;
+    if (persist < 0) persist = getenv("SWC_GEMM_NOPERSIST") ? 0 : 1;
+    const long slots = 256L * (WM * WN == 4 ? 2 : 1);
+    const long grid = (persist && nwg > slots) ? slots : nwg;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), LDS, s, p);
     return SWC_OK;
 }
 
