@@ -65,11 +65,14 @@ def fold_weight_norm(g, v):
 
 
 class Oracle:
-    def __init__(self, generator_params, state_dict, num_threads=None):
+    def __init__(self, generator_params, state_dict, num_threads=None, dtype=torch.float32):
+        """dtype=torch.float64 runs the same algorithm in double on the same float32 weights: the
+        rounding-free yardstick tools/code_agreement.py measures every float32 implementation against."""
         self.gp = generator_params
+        self.dtype = dtype
         if num_threads:
             torch.set_num_threads(num_threads)
-        sd = {k: v.detach().clone() for k, v in state_dict.items()}
+        sd = {k: (v.detach().to(dtype, copy=True) if v.is_floating_point() else v.detach().clone()) for k, v in state_dict.items()}
         # fold weight norm once (the reference recomputes it every forward through the hook)
         for k in [k for k in sd if k.endswith(".weight_g")]:
             p = k[: -len("weight_g")]
@@ -84,7 +87,7 @@ class Oracle:
         self.eps = q.get("eps", 1e-3)
         self.heads_e = generator_params["acoustic_encoder"]["encoder_attention_heads"]
         self.heads_d = generator_params["acoustic_decoder"]["decoder_attention_heads"]
-        self.mel_fb = torch.from_numpy(slaney_mel_filters()).to(torch.float32)  # (201, 80)
+        self.mel_fb = torch.from_numpy(slaney_mel_filters()).to(torch.float32).to(dtype)  # (201, 80)
         self.stack = generator_params["downsample"]["stack_factor"]
         self.n_fft_v = generator_params["vocos"]["n_fft"]
         self.hop_v = generator_params["vocos"]["hop_size"]
@@ -98,13 +101,13 @@ class Oracle:
         per-utterance floor at max-8, (x+4)/4.  Returns mel (B,80,3000), mel_lens (B,)
         = number of samples-mask entries at stride 160 = ceil(n/160) (:237, model.py:191)."""
         B = len(wavs)
-        x = torch.zeros(B, N_SAMPLES)
+        x = torch.zeros(B, N_SAMPLES, dtype=self.dtype)
         lens = []
         for i, w in enumerate(wavs):
             w = torch.as_tensor(w, dtype=torch.float32).reshape(-1)[:N_SAMPLES]
             x[i, : w.numel()] = w
             lens.append((w.numel() + HOP - 1) // HOP)
-        st = torch.stft(x, N_FFT, HOP, window=torch.hann_window(N_FFT), return_complex=True)
+        st = torch.stft(x, N_FFT, HOP, window=torch.hann_window(N_FFT).to(self.dtype), return_complex=True)
         power = st[..., :-1].abs() ** 2
         mel = self.mel_fb.T @ power
         lg = torch.clamp(mel, min=1e-10).log10()
@@ -338,7 +341,7 @@ class Oracle:
             return {"codes_list": []}
         n = torch.tensor([len(w) for w in wav_list], dtype=torch.long)
         L = int(n.max())
-        x = torch.zeros(B, 1, L)
+        x = torch.zeros(B, 1, L, dtype=self.dtype)
         for i, w in enumerate(wav_list):
             x[i, 0, : len(w)] = torch.as_tensor(w, dtype=torch.float32)
         parts = []
