@@ -6,10 +6,21 @@
 
 namespace {
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// Sum over the 64 lanes on the DPP path (no LDS crossbar round trips): xor 1, xor 2, half-row mirror and row
+// mirror leave each row of 16 lanes holding its row sum; row_bcast:15 / row_bcast:31 chain the four rows into
+// lane 63, which is read into an SGPR (the result is wave-uniform).  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);  // row_mirror
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 template <typename OutT>
@@ -71,7 +82,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
         }
     }
-    const float mean = wave_sum(s) / (float)C;
+    const float mean = wave_sum_dpp(s) / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
@@ -81,7 +92,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             q += (a * a + bb * bb) + (c * c + d * d);
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+    const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) / (float)C + eps);
 #pragma unroll
     for (int k = 0; k < LN_MAXV; ++k) {
         const int i = lane + 64 * k;
@@ -95,63 +106,157 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------- depthwise k7 conv + LayerNorm
-constexpr int DW_MAXV = 4;  // C <= 1024
+// Strip kernel: a workgroup stages S+6 consecutive frames of one utterance in LDS, so every input row crosses
+// the vector-memory path once (plus the 6-row halo) instead of 7 times, and keeps the 7xC taps, the bias and
+// the LayerNorm affine in registers for the whole strip; each wave then turns out S/4 frames from LDS.
+// HBM traffic per frame: C*4 B in (f32 residual stream) + C*sizeof(OutT) out.
+constexpr int DW_MAXV = 4;  // float4 per lane: C <= 1024
+constexpr int DW_FG = 4;    // frames a wave finishes together (their reductions overlap)
 
-template <typename OutT>
-__global__ __launch_bounds__(256) void dwconv7_ln_kernel(const float* __restrict__ x, OutT* __restrict__ y,
-                                                         const float* __restrict__ w,     // [7][C]
-                                                         const float* __restrict__ bias,  // [C]
-                                                         const float* __restrict__ lw,
-                                                         const float* __restrict__ lb, long rows, int T,
-                                                         int C, float eps) {
+// rows t0-3 .. t0+S+2 of strip `sid` -> registers (row wv + 4r for r < NR); all loads in flight together
+template <int NK, int S, bool FULL>
+__device__ __forceinline__ void dw_fetch(float4 (&st)[(S + 6 + 3) / 4][NK], const float* __restrict__ x, int sid,
+                                         int nst, int T, int nv, int wv, int lane) {
+    const int b = sid / nst, t0 = (sid - b * nst) * S;
+    const float4* xb = reinterpret_cast<const float4*>(x) + ((long)b * T + t0 - 3) * nv + lane;
+#pragma unroll
+    for (int r = 0; r < (S + 6 + 3) / 4; ++r) {
+        const int rr = wv + 4 * r, ts = t0 + rr - 3;  // wave-uniform
+        const bool in = rr < S + 6 && ts >= 0 && ts < T;  // zero padding per utterance (Conv1d padding=3)
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            if (in && (FULL || lane + 64 * k < nv)) st[r][k] = xb[(long)rr * nv + 64 * k];
+            else st[r][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+// FULL: C == 1024 * NK / 4 exactly (every lane owns NK float4 of a row), no per-lane predicates
+template <typename OutT, int NK, int S, bool FULL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void dwconv7_ln_kernel(const float* __restrict__ x, OutT* __restrict__ y,
+                       const float* __restrict__ w,     // [7][C]
+                       const float* __restrict__ bias,  // [C]
+                       const float* __restrict__ lw, const float* __restrict__ lb, int T, int C, int nst,
+                       int nstrips, int per, float eps) {
+    extern __shared__ float4 dw_sm[];  // [S + 6][C / 4]
     const int lane = threadIdx.x & 63;
-    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= rows) return;
-    const int b = (int)(r / T), t = (int)(r - (long)b * T);
-    const float* xb = x + (long)b * T * C;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nv = C >> 2;
-    float4 v[DW_MAXV];
-    float s = 0.f;
+    const float inv_c = 1.0f / (float)C;
+    constexpr int NR = (S + 6 + 3) / 4;
+    float4 st[NR][NK];
+    // each workgroup walks `per` consecutive strips (the halo rows it re-reads were just loaded), and the
+    // workgroups of one XCD (blockIdx % 8) own one contiguous range of strips, so neighbours share an L2
+    const int per_xcd = gridDim.x >> 3;
+    const int order = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    int sid = order * per;
+    const int send = min(sid + per, nstrips);
+    if (sid >= send) return;
+    dw_fetch<NK, S, FULL>(st, x, sid, nst, T, nv, wv, lane);
+    float4 wr[7][NK], br[NK], gw[NK], gb[NK];
 #pragma unroll
-    for (int k = 0; k < DW_MAXV; ++k) {
+    for (int k = 0; k < NK; ++k) {
         const int i = lane + 64 * k;
-        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < nv) {
-            float4 a = *reinterpret_cast<const float4*>(bias + 4 * i);
+        if (FULL || i < nv) {
 #pragma unroll
-            for (int j = 0; j < 7; ++j) {
-                const int ts = t + j - 3;
-                if (ts >= 0 && ts < T) {
-                    const float4 xv = *reinterpret_cast<const float4*>(xb + (long)ts * C + 4 * i);
-                    const float4 wv = *reinterpret_cast<const float4*>(w + (long)j * C + 4 * i);
-                    a.x += xv.x * wv.x; a.y += xv.y * wv.y; a.z += xv.z * wv.z; a.w += xv.w * wv.w;
+            for (int j = 0; j < 7; ++j) wr[j][k] = reinterpret_cast<const float4*>(w + (long)j * C)[i];
+            br[k] = reinterpret_cast<const float4*>(bias)[i];
+            gw[k] = reinterpret_cast<const float4*>(lw)[i];
+            gb[k] = reinterpret_cast<const float4*>(lb)[i];
+        } else {
+            const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) wr[j][k] = z4;
+            br[k] = gw[k] = gb[k] = z4;
+        }
+    }
+    constexpr int PER = S / 4;
+    static_assert(PER % DW_FG == 0, "strip = 4 waves x groups of DW_FG frames");
+    // persistent walk: while a strip is computed from LDS the next one is already in flight to registers
+    for (;;) {
+        const int b = sid / nst, t0 = (sid - b * nst) * S;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int rr = wv + 4 * r;
+            if (rr < S + 6) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k)
+                    if (FULL || lane + 64 * k < nv) dw_sm[rr * nv + lane + 64 * k] = st[r][k];
+            }
+        }
+        __syncthreads();
+        const int nxt = sid + 1;
+        if (nxt < send) dw_fetch<NK, S, FULL>(st, x, nxt, nst, T, nv, wv, lane);
+        for (int g = 0; g < PER / DW_FG; ++g) {
+            const int f0 = wv * PER + g * DW_FG;
+            if (t0 + f0 >= T) break;
+            float4 v[DW_FG][NK];
+            float sum[DW_FG], sq[DW_FG];
+#pragma unroll
+            for (int u = 0; u < DW_FG; ++u) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) v[u][k] = br[k];
+            }
+            // rows f0 .. f0+DW_FG+5, each read once; frame u takes row p as tap j = p - u (taps in order 0..6)
+            const float4* rows = dw_sm + f0 * nv + lane;
+#pragma unroll
+            for (int pr = 0; pr < DW_FG + 6; ++pr) {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    if (FULL || lane + 64 * k < nv) {
+                        const float4 xv = rows[pr * nv + 64 * k];
+#pragma unroll
+                        for (int u = 0; u < DW_FG; ++u) {
+                            const int j = pr - u;
+                            if (j >= 0 && j < 7) {
+                                v[u][k].x += xv.x * wr[j][k].x; v[u][k].y += xv.y * wr[j][k].y;
+                                v[u][k].z += xv.z * wr[j][k].z; v[u][k].w += xv.w * wr[j][k].w;
+                            }
+                        }
+                    }
                 }
             }
-            v[k] = a;
-            s += (a.x + a.y) + (a.z + a.w);
-        }
-    }
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < DW_MAXV; ++k) {
-        const int i = lane + 64 * k;
-        if (i < nv) {
-            const float a = v[k].x - mean, bb = v[k].y - mean, c = v[k].z - mean, d = v[k].w - mean;
-            q += (a * a + bb * bb) + (c * c + d * d);
-        }
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-    OutT* yr = y + r * C;
+            for (int u = 0; u < DW_FG; ++u) {
+                sum[u] = 0.f;
 #pragma unroll
-    for (int k = 0; k < DW_MAXV; ++k) {
-        const int i = lane + 64 * k;
-        if (i < nv) {
-            const float4 ww = *reinterpret_cast<const float4*>(lw + 4 * i);
-            const float4 bb = *reinterpret_cast<const float4*>(lb + 4 * i);
-            store4<OutT>(yr + 4 * i, (v[k].x - mean) * rstd * ww.x + bb.x, (v[k].y - mean) * rstd * ww.y + bb.y,
-                         (v[k].z - mean) * rstd * ww.z + bb.z, (v[k].w - mean) * rstd * ww.w + bb.w);
+                for (int k = 0; k < NK; ++k) sum[u] += (v[u][k].x + v[u][k].y) + (v[u][k].z + v[u][k].w);
+            }
+#pragma unroll
+            for (int u = 0; u < DW_FG; ++u) sum[u] = wave_sum_dpp(sum[u]);
+#pragma unroll
+            for (int u = 0; u < DW_FG; ++u) {
+                const float mean = sum[u] * inv_c;
+                sq[u] = 0.f;
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    v[u][k].x -= mean; v[u][k].y -= mean; v[u][k].z -= mean; v[u][k].w -= mean;
+                    if (FULL || lane + 64 * k < nv)
+                        sq[u] += (v[u][k].x * v[u][k].x + v[u][k].y * v[u][k].y) +
+                                 (v[u][k].z * v[u][k].z + v[u][k].w * v[u][k].w);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < DW_FG; ++u) sq[u] = wave_sum_dpp(sq[u]);
+            OutT* yr = y + ((long)b * T + t0 + f0) * C + 4 * lane;
+#pragma unroll
+            for (int u = 0; u < DW_FG; ++u) {
+                if (t0 + f0 + u < T) {  // wave-uniform
+                    const float rstd = rsqrtf(sq[u] * inv_c + eps);
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        if (FULL || lane + 64 * k < nv)
+                            store4<OutT>(yr + (long)u * C + 256 * k, v[u][k].x * rstd * gw[k].x + gb[k].x,
+                                         v[u][k].y * rstd * gw[k].y + gb[k].y, v[u][k].z * rstd * gw[k].z + gb[k].z,
+                                         v[u][k].w * rstd * gw[k].w + gb[k].w);
+                    }
+                }
+            }
         }
+        if (nxt >= send) break;
+        sid = nxt;
+        __syncthreads();  // every wave is done with this strip's rows
     }
 }
 
@@ -509,20 +614,62 @@ extern "C" int swc_layernorm(const float* x, void* y, const float* w, const floa
     return SWC_OK;
 }
 
+template <typename OutT, int NK, int S, bool FULL>
+static int launch_dwconv7_ln(const float* x, void* y, const float* w, const float* bias, const float* ln_w,
+                             const float* ln_b, int B, int T, int C, float eps, hipStream_t s) {
+    const int lds = (S + 6) * C * 4;
+    auto kern = dwconv7_ln_kernel<OutT, NK, S, FULL>;
+    if (lds > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) {
+                swc_set_error("swc_dwconv7_ln: cannot enable %d bytes of LDS: %s", lds, hipGetErrorString(e));
+                return SWC_E_LAUNCH;
+            }
+            attr_set = true;
+        }
+    }
+    const int nst = (T + S - 1) / S, nstrips = nst * B;
+    // resident workgroups: LDS-limited per CU, 256 CUs; each walks nstrips / grid strips
+    static const int wgs = getenv("SWC_DW_WGS") ? atoi(getenv("SWC_DW_WGS")) : 0;
+    const int fit = 160 * 1024 / lds;
+    const int slots = 256 * (wgs > 0 ? wgs : (fit > 2 ? 2 : fit));  // <= 2 waves per SIMD by registers
+    const int per = (nstrips + slots - 1) / slots;           // consecutive strips per workgroup
+    const int grid = ((nstrips + per - 1) / per + 7) & ~7;   // multiple of 8: one contiguous strip range per XCD
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, x, (OutT*)y, w, bias, ln_w, ln_b, T, C, nst, nstrips,
+                       per, eps);
+    return SWC_OK;
+}
+
 extern "C" int swc_dwconv7_ln(const float* x, void* y, const float* w, const float* bias, const float* ln_w,
                               const float* ln_b, int32_t B, int32_t T, int32_t C, float eps, int32_t y_dtype,
                               void* stream) {
     SWC_CHECK_ARG(x && y && w && bias && ln_w && ln_b, "swc_dwconv7_ln: null pointer");
     SWC_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * DW_MAXV, "swc_dwconv7_ln: C=%d unsupported", C);
     SWC_CHECK_ARG(y_dtype == SWC_F32 || y_dtype == SWC_BF16, "swc_dwconv7_ln: bad dtype");
-    const long rows = (long)B * T;
-    if (rows <= 0) return SWC_OK;
+    if ((long)B * T <= 0) return SWC_OK;
     hipStream_t s = (hipStream_t)stream;
-    OUT_DISPATCH(y_dtype,
-                 hipLaunchKernelGGL(dwconv7_ln_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (float*)y,
-                                    w, bias, ln_w, ln_b, rows, T, C, eps),
-                 hipLaunchKernelGGL(dwconv7_ln_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, s, x,
-                                    (bf16_t*)y, w, bias, ln_w, ln_b, rows, T, C, eps));
+    int rc;
+#define DW_GO(NK_, S_)                                                                                            \
+    do {                                                                                                          \
+        if (C == 256 * NK_)                                                                                       \
+            rc = y_dtype == SWC_BF16                                                                              \
+                     ? launch_dwconv7_ln<bf16_t, NK_, S_, true>(x, y, w, bias, ln_w, ln_b, B, T, C, eps, s)       \
+                     : launch_dwconv7_ln<float, NK_, S_, true>(x, y, w, bias, ln_w, ln_b, B, T, C, eps, s);       \
+        else                                                                                                      \
+            rc = y_dtype == SWC_BF16                                                                              \
+                     ? launch_dwconv7_ln<bf16_t, NK_, S_, false>(x, y, w, bias, ln_w, ln_b, B, T, C, eps, s)      \
+                     : launch_dwconv7_ln<float, NK_, S_, false>(x, y, w, bias, ln_w, ln_b, B, T, C, eps, s);      \
+    } while (0)
+    // strips of 16 frames: (16+6) rows of LDS per workgroup, two workgroups per CU (register-limited)
+    static const int forced = getenv("SWC_DW_STRIP") ? atoi(getenv("SWC_DW_STRIP")) : 0;
+    if (C <= 256) { DW_GO(1, 32); }
+    else if (C <= 512) { if (forced == 32) { DW_GO(2, 32); } else { DW_GO(2, 16); } }
+    else { DW_GO(4, 16); }
+#undef DW_GO
+    if (rc != SWC_OK) return rc;
     SWC_CHECK_LAUNCH("swc_dwconv7_ln");
     return SWC_OK;
 }

@@ -168,7 +168,7 @@ def test_layernorm(C):
     assert _rel(o2.float(), F.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-6)) < 8e-3
 
 
-@pytest.mark.parametrize("C,T", [(512, 100), (64, 9)])
+@pytest.mark.parametrize("C,T", [(512, 100), (64, 9), (512, 1), (260, 33), (768, 70), (1024, 37), (512, 1000)])
 def test_dwconv7_ln(C, T):
     ops = _ops()
     B = 2
@@ -181,6 +181,9 @@ def test_dwconv7_ln(C, T):
     out = ops.dwconv7_ln(x.transpose(1, 2).contiguous().to(DEV), w[:, 0].T.contiguous().to(DEV), b.to(DEV),
                          lw.to(DEV), lb.to(DEV), 1e-6, B=B, T=T, C_=C)
     assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+    o2 = ops.dwconv7_ln(x.transpose(1, 2).contiguous().to(DEV), w[:, 0].T.contiguous().to(DEV), b.to(DEV),
+                        lw.to(DEV), lb.to(DEV), 1e-6, B=B, T=T, C_=C, out_dtype=torch.bfloat16)
+    assert _rel(o2.float(), ref) < 8e-3
 
 
 def _kaiser_sinc12():
