@@ -33,6 +33,7 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 
 // `s_waitcnt vmcnt(N)` + barrier (cdna_hip_programming.md 5.7).  M0 is saved/restored inside the statement.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
     unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);  // wave-uniform by construction; pin it to an SGPR
     asm volatile(
         "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
         : "=&s"(keep)
@@ -167,7 +168,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
     }
 }
 
-template <int MODE, typename OutT, int MT, int WAVES_M, int WAVES_N, int RB = 128>
+// PLAIN: one tap, K a multiple of the slice, no stride / padding / row remap — the hot GEMMs.  A separate
+// instantiation so that the implicit-conv bookkeeping (~32 VGPRs) does not sit in the hot loop's register budget.
+template <int MODE, typename OutT, int MT, int WAVES_M, int WAVES_N, bool PLAIN, int RB = 128>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p) {
     constexpr int ROW_BYTES = RB;  // bytes of K per LDS row per slice: 128, or 64 (bf16 / f32 only: smaller stages, two workgroups per CU)
     constexpr int CPR = RB / 16;   // 16-byte chunks per row
@@ -233,7 +236,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     // Lanes whose tap / K-chunk is out of range fetch a 16-byte device zero page (LDS-DMA cannot
     // zero-fill).  Rows beyond M / N are clamped instead (their results are never stored).
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    const bool plain = (p.taps == 1) && (p.K % BK == 0) && (p.stride == 1) && (p.pad == 0) && (p.t_in == p.t_out);
     const char* a_ptr[NA];
     const char* w_ptr[NB];
     auto setup_tile = [&](int local) {
@@ -242,23 +244,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         for (int i = 0; i < NA; ++i) {
             const int row = ld_row + RPS * i;
             const int r = bm + row;
-            a_rowok[i] = r < p.M;
-            const int rr = a_rowok[i] ? r : 0;
-            a_b[i] = rr / p.t_out;
-            a_t[i] = rr - a_b[i] * p.t_out;
-            a_chunk[i] = ld_pos ^ swz_rb<RB>(row);
-            const int rc = r < p.M ? r : p.M - 1;
-            a_ptr[i] = p.A + ((long)rc * p.lda + a_chunk[i] * EPC) * ES;  // plain GEMM: t_in == t_out == M
+            const int chunk = ld_pos ^ swz_rb<RB>(row);
+            if constexpr (PLAIN) {
+                const int rc = r < p.M ? r : p.M - 1;  // rows beyond M are clamped (their results are never stored)
+                a_ptr[i] = p.A + ((long)rc * p.lda + chunk * EPC) * ES;
+            } else {
+                a_rowok[i] = r < p.M;
+                const int rr = a_rowok[i] ? r : 0;
+                a_b[i] = rr / p.t_out;
+                a_t[i] = rr - a_b[i] * p.t_out;
+                a_chunk[i] = chunk;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int row = ld_row + RPS * i;
             const int n = bn + row;
-            w_rowok[i] = n < p.N;
-            w_rowoff[i] = (long)(w_rowok[i] ? n : 0) * p.ldw;
-            w_chunk[i] = ld_pos ^ swz_rb<RB>(row);
-            const int nc = n < p.N ? n : p.N - 1;
-            w_ptr[i] = p.W + ((long)nc * p.ldw + w_chunk[i] * EPC) * ES;
+            const int chunk = ld_pos ^ swz_rb<RB>(row);
+            if constexpr (PLAIN) {
+                const int nc = n < p.N ? n : p.N - 1;
+                w_ptr[i] = p.W + ((long)nc * p.ldw + chunk * EPC) * ES;
+            } else {
+                w_rowok[i] = n < p.N;
+                w_rowoff[i] = (long)(w_rowok[i] ? n : 0) * p.ldw;
+                w_chunk[i] = chunk;
+            }
         }
     };
     setup_tile(tl);
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         const unsigned sa = smem_base + stage * STAGE_BYTES + wave_u * 1024;  // one wave-instruction = 1 KiB of rows
         const unsigned sb = sa + A_BYTES;
         if (p.dbg & 1) return;
-        if (plain) {
+        if constexpr (PLAIN) {
             const long koff = (long)kt * ROW_BYTES;
 #pragma unroll
             for (int i = 0; i < NA; ++i) glds16(a_ptr[i] + koff, sa + RPS * i * ROW_BYTES);
@@ -403,8 +413,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     }
 }
 
-template <int MODE, typename OutT, int MT, int WM, int WN, int RB = 128>
-int launch(GemmP p, hipStream_t s) {
+template <int MODE, typename OutT, int MT, int WM, int WN, bool PLAIN, int RB = 128>
+int launch_k(GemmP p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * 64;
     constexpr int LDS = 2 * (BM + BN) * RB;
     {
@@ -423,7 +433,7 @@ int launch(GemmP p, hipStream_t s) {
         swc_set_error("swc_gemm: grid too large");
         return SWC_E_ARG;
     }
-    auto kern = gemm_kernel<MODE, OutT, MT, WM, WN, RB>;
+    auto kern = gemm_kernel<MODE, OutT, MT, WM, WN, PLAIN, RB>;
     if (LDS > 64 * 1024) {
         static bool attr_set = false;  // per instantiation; benign race (same value)
         if (!attr_set) {
@@ -445,6 +455,12 @@ int launch(GemmP p, hipStream_t s) {
     return SWC_OK;
 }
 
+template <int MODE, typename OutT, int MT, int WM, int WN, int RB = 128>
+int launch(GemmP p, hipStream_t s) {
+    constexpr int BK = RB / (MODE == SWC_BF16 ? 2 : 4);
+    const bool plain = (p.taps == 1) && (p.K % BK == 0) && (p.stride == 1) && (p.pad == 0) && (p.t_in == p.t_out);
+    return plain ? launch_k<MODE, OutT, MT, WM, WN, true, RB>(p, s) : launch_k<MODE, OutT, MT, WM, WN, false, RB>(p, s);
+}
 
 }  // namespace
 
