@@ -73,7 +73,8 @@ __device__ __forceinline__ float gelu_erf(float x) {
 
 // GELU for bf16 OUTPUTS only: x * sigmoid(2u), u = 0.80015708 (x + 0.0433676 x^3) — the tanh form with its two
 // constants re-fitted (minimax) to the exact erf GELU: |error| <= 2.7e-4 everywhere, against a bf16 output
-// rounding of up to 7.8e-3 on |x| < 4.  5 VALU + 2 transcendental ops; the exact-erf path costs ~4x that and made
+// rounding of up to 7.8e-3 on |x| < 4.  5 VALU + 2 transcendental ops (36 issue cycles; a transcendental-free 7-term
+// packed polynomial, |error| 1.5e-4, was measured slower: v_pk_*_f32 issues at half rate); the exact-erf path costs ~4x that and made
 // the pwconv1 / fc1 epilogues VALU-bound.  f32 / split-f16 outputs keep erff.
 __device__ __forceinline__ float gelu_fast(float x) {
     const float k0 = 0.80015708f * 2.885390081777927f;              // 2 log2(e) * c0

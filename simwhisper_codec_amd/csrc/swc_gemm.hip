@@ -40,6 +40,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_addr) {
         : "v"(gsrc), "s"(lds_addr)
         : "memory");
 }
+// same, address = wave-uniform 64-bit base (SGPR pair) + per-lane unsigned 32-bit byte offset: one VGPR per lane
+// instead of a 64-bit pointer per staged row
+__device__ __forceinline__ void glds16_s(const char* base, unsigned off, unsigned lds_addr) {
+    unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(off), "s"(base), "s"(lds_addr)
+        : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -236,19 +247,32 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     // Lanes whose tap / K-chunk is out of range fetch a 16-byte device zero page (LDS-DMA cannot
     // zero-fill).  Rows beyond M / N are clamped instead (their results are never stored).
     const unsigned smem_base = __builtin_amdgcn_readfirstlane(lds_addr_of(smem));
-    const char* a_ptr[NA];
-    const char* w_ptr[NB];
+    // PLAIN staging: address = wave-uniform tile base (SGPRs) + one 32-bit offset per lane.  Row r of a sweep sits at
+    // r * ld_bytes + (chunk << 4); the swizzled chunk repeats every 64 rows, so NV (1 or 2) per-lane constants cover
+    // all sweeps, and rows beyond M / N are clamped to the last valid row (their results are never stored).
+    constexpr int NV = RPS >= 64 ? 1 : 64 / RPS;
+    unsigned chunkoff[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) chunkoff[v] = (unsigned)(ld_pos ^ swz_rb<RB>(ld_row + RPS * v)) << 4;
+    const unsigned lda_bytes = (unsigned)(p.lda * ES), ldw_bytes = (unsigned)(p.ldw * ES);  // < 2^24 (host check)
+    const char* a_base = p.A;
+    const char* w_base = p.W;
+    int a_left = 1, w_left = 1;
     auto setup_tile = [&](int local) {
         tile_origin(local);
+        if constexpr (PLAIN) {
+            a_base = p.A + (long)bm * lda_bytes;
+            w_base = p.W + (long)bn * ldw_bytes;
+            a_left = p.M - bm;
+            w_left = p.N - bn;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int row = ld_row + RPS * i;
             const int r = bm + row;
             const int chunk = ld_pos ^ swz_rb<RB>(row);
-            if constexpr (PLAIN) {
-                const int rc = r < p.M ? r : p.M - 1;  // rows beyond M are clamped (their results are never stored)
-                a_ptr[i] = p.A + ((long)rc * p.lda + chunk * EPC) * ES;
-            } else {
+            if constexpr (!PLAIN) {
                 a_rowok[i] = r < p.M;
                 const int rr = a_rowok[i] ? r : 0;
                 a_b[i] = rr / p.t_out;
@@ -261,10 +285,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
             const int row = ld_row + RPS * i;
             const int n = bn + row;
             const int chunk = ld_pos ^ swz_rb<RB>(row);
-            if constexpr (PLAIN) {
-                const int nc = n < p.N ? n : p.N - 1;
-                w_ptr[i] = p.W + ((long)nc * p.ldw + chunk * EPC) * ES;
-            } else {
+            if constexpr (!PLAIN) {
                 w_rowok[i] = n < p.N;
                 w_rowoff[i] = (long)(w_rowok[i] ? n : 0) * p.ldw;
                 w_chunk[i] = chunk;
@@ -278,10 +299,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         if (p.dbg & 1) return;
         if constexpr (PLAIN) {
             const long koff = (long)kt * ROW_BYTES;
+            const char* ab = a_base + koff;
+            const char* wb = w_base + koff;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) glds16(a_ptr[i] + koff, sa + RPS * i * ROW_BYTES);
+            for (int i = 0; i < NA; ++i) {
+                const int r = min(ld_row + RPS * i, a_left - 1);
+                glds16_s(ab, __umul24(r, lda_bytes) + chunkoff[i % NV], sa + RPS * i * ROW_BYTES);
+            }
 #pragma unroll
-            for (int i = 0; i < NB; ++i) glds16(w_ptr[i] + koff, sb + RPS * i * ROW_BYTES);
+            for (int i = 0; i < NB; ++i) {
+                const int r = min(ld_row + RPS * i, w_left - 1);
+                glds16_s(wb, __umul24(r, ldw_bytes) + chunkoff[i % NV], sb + RPS * i * ROW_BYTES);
+            }
             return;
         }
         const int tap = kt / p.kc_per_tap;
@@ -458,7 +487,9 @@ int launch_k(GemmP p, hipStream_t s) {
 template <int MODE, typename OutT, int MT, int WM, int WN, int RB = 128>
 int launch(GemmP p, hipStream_t s) {
     constexpr int BK = RB / (MODE == SWC_BF16 ? 2 : 4);
-    const bool plain = (p.taps == 1) && (p.K % BK == 0) && (p.stride == 1) && (p.pad == 0) && (p.t_in == p.t_out);
+    const long es = MODE == SWC_BF16 ? 2 : 4;
+    const bool plain = (p.taps == 1) && (p.K % BK == 0) && (p.stride == 1) && (p.pad == 0) && (p.t_in == p.t_out) &&
+                       p.lda * es < (1L << 24) && p.ldw * es < (1L << 24);  // 24-bit row pitch: offsets by v_mul_u32_u24
     return plain ? launch_k<MODE, OutT, MT, WM, WN, true, RB>(p, s) : launch_k<MODE, OutT, MT, WM, WN, false, RB>(p, s);
 }
 
