@@ -364,7 +364,7 @@ class AudioCodec(nn.Module):
         c1 = self._mm(mel, P.c1w, B * Tm, D, P.n_mel, lda=P.n_mel, ldw=3 * P.n_mel, bias=P.c1b, taps=3, pad=1, t_in=Tm,
                       t_out=Tm, out_dtype=dt)
         h = self._mm(c1, P.c2w, B * Ttok, D, D, lda=D, ldw=3 * D, bias=P.c2b, taps=3, stride=2, pad=1, t_in=Tm, t_out=Ttok)
-        lens = torch.tensor(tok_host, dtype=torch.int32, device=dev)
+        lens = self._dev_ints(tok_host, dev)
         self._transformer(h, lens, B, Ttok, P.enc_layers, P.He, dt)
         s = P.stack
         tds_full = spec.cdiv(t_full, s)
@@ -387,7 +387,7 @@ class AudioCodec(nn.Module):
         x = self._mm(self._cast(h, dt), P.tsw, B * T, s * D, P.uhid, lda=P.uhid, bias=P.tsb)
         Tt = s * T
         x = x.view(B * Tt, D)
-        lens = torch.tensor([l * s for l in lat_host], dtype=torch.int32, device=dev)
+        lens = self._dev_ints([l * s for l in lat_host], dev)
         self._transformer(x, lens, B, Tt, P.dec_layers, P.Hd, dt)
         hn = ops.layernorm(x, P.dec_ln[0], P.dec_ln[1], 1e-5, B=B, t_in=Tt, C_=D, lens=lens, out_dtype=dt)
         y3 = self._mm(hn, P.d1w, B * Tt, 3 * D, D, lda=D)
@@ -413,6 +413,33 @@ class AudioCodec(nn.Module):
         fr = self._mm(sp, P.idft, M, 640, 648, lda=648)
         return ops.istft_ola(fr, P.wsq, B=B, T=Tv)
 
+    # short int lists (lengths) go to the device through a ring of pinned staging rows with non-blocking copies:
+    # torch.tensor(list, device=...) copies from pageable memory and synchronises the stream every time
+    _PIN_SLOTS, _PIN_LEN = 32, 4096
+
+    def _dev_ints(self, values, dev):
+        n = len(values)
+        dev = torch.device(dev)
+        if n == 0 or n > self._PIN_LEN or dev.type != "cuda":
+            return torch.tensor(values, dtype=torch.int32, device=dev)
+        st = self.__dict__.get("_pin")
+        if st is None or st["dev"] != dev:
+            st = {"dev": dev, "buf": torch.empty((self._PIN_SLOTS, self._PIN_LEN), dtype=torch.int32).pin_memory(),
+                  "ev": [None] * self._PIN_SLOTS, "i": 0}
+            self.__dict__["_pin"] = st
+        i = st["i"]
+        st["i"] = (i + 1) % self._PIN_SLOTS
+        if st["ev"][i] is not None:
+            st["ev"][i].synchronize()  # the copy that last used this row finished 32 uploads ago
+        row = st["buf"][i, :n]
+        row.copy_(torch.tensor(values, dtype=torch.int32))
+        out = torch.empty(n, dtype=torch.int32, device=dev)
+        out.copy_(row, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        st["ev"][i] = ev
+        return out
+
     # ------------------------------------------------- reference entry points
     @torch.inference_mode()
     def inference_tokenize(self, x, input_lengths):
@@ -425,12 +452,12 @@ class AudioCodec(nn.Module):
         if wav.stride(-1) != 1:
             wav = wav.contiguous()
         dev = wav.device
-        n_dev = torch.tensor(n_host, dtype=torch.int32, device=dev)
+        n_dev = self._dev_ints(n_host, dev)
         mel, Tm = self._logmel(wav, n_dev, n_host, P)
         tok = [spec.token_len(n) for n in n_host]
         z, Tds, lat = self._encode_mel(mel, Tm, spec.MEL_FRAMES // 2, tok, P)
         t_pad = spec.cdiv(spec.MEL_FRAMES // 2, P.stack)  # 375: the reference always returns the padded length
-        lat_dev = torch.tensor(lat, dtype=torch.int32, device=dev)
+        lat_dev = self._dev_ints(lat, dev)
         zq, codes = ops.fsq_encode(z, P.lat, lat_dev, P.fsq, B=B, T=Tds, t_pad=t_pad, G=self.num_groups)
         return {"zq": zq.transpose(1, 2), "codes": codes, "codes_lengths": lat_dev.long()}
 
@@ -441,7 +468,7 @@ class AudioCodec(nn.Module):
         G, B, T = codes.shape
         lat = [int(v) for v in (codes_lengths.tolist() if torch.is_tensor(codes_lengths) else codes_lengths)]
         dev = codes.device
-        lat_dev = torch.tensor(lat, dtype=torch.int32, device=dev)
+        lat_dev = self._dev_ints(lat, dev)
         zq = ops.fsq_decode(codes.to(torch.int64).contiguous(), lat_dev, B=B, T=T, G=G)
         wav = self._decode_latent(zq, lat, B, T, P)
         return {"y": wav[:, None, :], "output_length": lat_dev.long() * self.decoder_upsample_rate}
