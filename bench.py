@@ -30,7 +30,7 @@ import yaml  # noqa: E402
 
 # MI355X dense MFMA peaks (MI355X_MICROARCH.md).  gemm_f16s executes 3 f16 MFMA passes per algorithmic
 # multiply-add (hi*hi + hi*lo + lo*hi), so its ceiling in algorithmic FLOP/s is 2500 / 3.
-PEAK_TFLOPS = {"gemm_bf16": 2500.0, "gemm_f32": 157.3, "gemm_f16s": 2500.0 / 3.0}
+PEAK_TFLOPS = {"gemm_bf16": 2500.0, "gemm_f32": 157.3, "gemm_f16s": 2500.0 / 3.0, "gemm_fp8": 5000.0}
 
 
 class GemmTimer:
@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--precision", default="mixed", choices=["fp32", "mixed", "mixed_f32", "bf16"])
+    ap.add_argument("--precision", default="mixed", choices=["fp32", "mixed", "mixed_f32", "bf16", "fp8"])
     ap.add_argument("--cpu-utts", type=int, default=4, help="utterances in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-gemm-timer", action="store_true")
     args = ap.parse_args()
@@ -160,7 +160,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "mixed": "split-f16 x3 encode (f32-class, f32 accumulate) / bf16 decode (f32 accumulate)",
-                      "mixed_f32": "f32 encode / bf16 decode (f32 accumulate)", "bf16": "bf16"}[args.precision],
+                      "mixed_f32": "f32 encode / bf16 decode (f32 accumulate)", "bf16": "bf16",
+                      "fp8": "fp8 (e4m3) encoder-transformer linears / bf16 elsewhere (f32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"batch={args.batch}x{args.seconds:g}s @16kHz per GPU, encode()+decode(), "
                                    f"synthetic closed-form checkpoint (291M params)",

@@ -47,6 +47,15 @@ extern "C" {
 /* scale 2^s of every split-f16 ACTIVATION written by swc_layernorm / swc_snake_aa / swc_attention_ex:
  * |x| up to 1023 without saturation, lo halves normal down to |x| ~ 2e-3 */
 #define SWC_F16S_ACT_SCALE 64.0f
+/*
+ * SWC_FP8 — OCP e4m3fn bytes (gfx950's native fp8; max 448, 3 mantissa bits), one byte per element, for the
+ * "fp8 Whisper-encoder GEMMs" preset (BASELINE.json configs[4]): swc_gemm contracts two fp8 operands with
+ * v_mfma_f32_16x16x32_fp8_fp8 (f32 accumulate).  Values are stored pre-multiplied by a power of two chosen by
+ * the caller (activations: SWC_FP8_ACT_SCALE; weights: per tensor) and un-done by `alpha`; conversions saturate
+ * at +-448.  This preset trades the bit-exact indices for speed: its tolerance is stated in DESIGN.md section 4.
+ */
+#define SWC_FP8 3
+#define SWC_FP8_ACT_SCALE 16.0f
 
 #define SWC_ACT_NONE 0
 #define SWC_ACT_GELU 1 /* exact erf GELU == nn.GELU() / ACT2FN["gelu"] */
@@ -73,9 +82,11 @@ int swc_device_count(void);
  *   b*t_in + t*stride + j*dil - pad   (zero if outside [0, t_in)).
  * A plain GEMM is taps=1, stride=1, dil=1, pad=0, t_in=t_out=M.
  * epilogue: v = alpha * acc + bias[n]; v = act(v); v *= gamma[n]; v += residual[r][n];
- *           C = (c_dtype == F16S) ? split(v * out_scale) : v.     (alpha == 0 is read as 1)
- * K must be a multiple of 4 (f32) / 8 (bf16) / 32 (f16s); lda, ldw keep rows 16-byte aligned.
+ *           C = (c_dtype == F16S) ? split(v * out_scale) : (c_dtype == FP8 ? e4m3(v * out_scale) : v).
+ *           (alpha == 0 is read as 1)
+ * K must be a multiple of 4 (f32) / 8 (bf16) / 32 (f16s) / 16 (fp8); lda, ldw keep rows 16-byte aligned.
  * a_dtype F16S: A and W are both split-f16; c_dtype F16S needs N % 32 == 0.
+ * a_dtype FP8: A and W are both e4m3 bytes; c_dtype FP8 is available for a_dtype FP8 only.
  */
 typedef struct swc_gemm_args {
     const void* A;
@@ -89,7 +100,7 @@ typedef struct swc_gemm_args {
     int32_t taps, dil, stride, pad, t_in, t_out;
     int32_t a_dtype, c_dtype, act;
     float alpha;     /* multiplies the accumulator (undoes operand scales); 0 means 1 */
-    float out_scale; /* F16S output only: 2^s applied before the split; 0 means 1 */
+    float out_scale; /* F16S / FP8 outputs only: 2^s applied before the split / conversion; 0 means 1 */
 } swc_gemm_args;
 int swc_gemm(const swc_gemm_args* args, void* stream);
 
@@ -118,7 +129,7 @@ int swc_attention_ex(const void* qkv, void* out, const int32_t* lens, int32_t B,
 /*
  * LayerNorm over the last dim.  Replaces nn.LayerNorm calls modules.py:216,224,
  * 353,457 (eps 1e-5) and :1239,1499,1503 (eps 1e-6).  x: [B][t_in][C] f32;
- * y: [B][t_out][C] (y_dtype).  Only rows t < min(t_in, t_out) are written; when lens != NULL
+ * y: [B][t_out][C] (y_dtype: F32 | BF16 | F16S at SWC_F16S_ACT_SCALE | FP8 at SWC_FP8_ACT_SCALE).  Only rows t < min(t_in, t_out) are written; when lens != NULL
  * rows t >= lens[b] are written as zeros (torch.where(mask, h, 0), modules.py:358,460).
  */
 int swc_layernorm(const float* x, void* y, const float* w, const float* b, const int32_t* lens,
@@ -217,6 +228,9 @@ int swc_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
 /* f32 [rows][ldx] (first K columns) -> split-f16 [rows][K] logical (K % 32 == 0), x scaled by `scale` */
 int swc_cast_f32_f16s(const float* x, int64_t ldx, void* y, int64_t rows, int32_t K, float scale,
                       void* stream);
+/* x (x_dtype F32 | BF16, n elements, n % 4 == 0) * scale -> e4m3 bytes, saturating (fp8 preset: weights at load,
+ * attention outputs) */
+int swc_cast_fp8(const void* x, int32_t x_dtype, void* y, int64_t n, float scale, void* stream);
 
 
 #ifdef __cplusplus

@@ -13,8 +13,9 @@ import torch  # noqa: F401  (must precede CDLL: shares PyTorch's HIP runtime)
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libswc_hip.so")
 
-F32, BF16, F16S = 0, 1, 2
+F32, BF16, F16S, FP8 = 0, 1, 2, 3
 F16S_ACT_SCALE = 64.0  # SWC_F16S_ACT_SCALE in include/swc.h
+FP8_ACT_SCALE = 16.0   # SWC_FP8_ACT_SCALE
 ACT_NONE, ACT_GELU = 0, 1
 
 
@@ -59,6 +60,7 @@ SIGNATURES = {
     "swc_codes_unpack": [_P, _P, _L, _I, _P],
     "swc_cast_f32_bf16": [_P, _P, _L, _P],
     "swc_cast_f32_f16s": [_P, _L, _P, _L, _I, _F, _P],
+    "swc_cast_fp8": [_P, _I, _P, _L, _F, _P],
 }
 PLAIN = {"swc_version": ([], C.c_int), "swc_last_error": ([], C.c_char_p), "swc_device_count": ([], C.c_int)}
 

@@ -33,7 +33,10 @@ from ._lib import SwcError
 #   f32  : exact-f32 MFMA (v_mfma_f32_16x16x4_f32)
 #   f16s : split-f16, 3 f16 MFMAs per k-step, f32-class accuracy (SWC_F16S in include/swc.h)
 #   bf16 : bf16 MFMA, f32 accumulate
-PRECISIONS = {"fp32": ("f32", "f32"), "mixed": ("f16s", "bf16"), "mixed_f32": ("f32", "bf16"), "bf16": ("bf16", "bf16")}
+#   fp8  : the `bf16` preset with the 48 encoder-transformer linears (qkv, out, fc1, fc2) on the fp8 MFMA (OCP e4m3fn,
+#          f32 accumulate; BASELINE.json configs[4]); codes are no longer bit-exact, tolerance in DESIGN.md section 4
+PRECISIONS = {"fp32": ("f32", "f32"), "mixed": ("f16s", "bf16"), "mixed_f32": ("f32", "bf16"), "bf16": ("bf16", "bf16"),
+              "fp8": ("bf16", "bf16")}
 _TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16s": torch.float16}
 
 
@@ -187,6 +190,10 @@ class AudioCodec(nn.Module):
             t = t.to(dev, torch.float32).contiguous()
             if dt == torch.bfloat16:
                 return _PW(ops.cast_bf16(t))
+            if dt == ops.FP8_T:  # per-tensor power-of-two scale: max|w| lands in [224, 448)
+                mx = float(t.abs().max())
+                sw = 2.0 ** math.floor(math.log2(448.0 / mx)) if mx > 0 else 1.0
+                return _PW(ops.cast_fp8(t, sw), 1.0 / (ops.FP8_ACT_SCALE * sw))
             if dt == torch.float16:
                 mx = float(t.abs().max())
                 sw = 2.0 ** math.floor(math.log2(16384.0 / mx)) if mx > 0 else 1.0
@@ -245,7 +252,8 @@ class AudioCodec(nn.Module):
         P.c1dt = c1dt
         P.c1w, P.c1b = W(conv_w(sd["acoustic_encoder.conv1.weight"]), c1dt), V(sd["acoustic_encoder.conv1.bias"])
         P.c2w, P.c2b = W(conv_w(sd["acoustic_encoder.conv2.weight"]), edt), V(sd["acoustic_encoder.conv2.bias"])
-        P.enc_layers = layers("acoustic_encoder", e["encoder_layers"], edt)
+        P.enc_ldt = ops.FP8_T if self._precision == "fp8" else edt  # operand type of the encoder-transformer linears
+        P.enc_layers = layers("acoustic_encoder", e["encoder_layers"], P.enc_ldt)
         P.enc_ln = (V(sd["acoustic_encoder.layer_norm.weight"]), V(sd["acoustic_encoder.layer_norm.bias"]))
         ds = gp["downsample"]
         P.stack, P.hid, P.lat = ds["stack_factor"], ds["hidden_dim"], ds["latent_dim"]
@@ -311,16 +319,22 @@ class AudioCodec(nn.Module):
         """swc_gemm against a packed weight; split-f16 outputs are written at the activation scale."""
         if out_dtype == torch.float16:
             kw["out_scale"] = ops.F16S_ACT_SCALE
+        elif out_dtype == ops.FP8_T:
+            kw["out_scale"] = ops.FP8_ACT_SCALE
         return ops.gemm(A, pw.w, M, N, K, alpha=pw.alpha, out_dtype=out_dtype, **kw)
 
     def _transformer(self, h, lens, B, T, layers, H, dt):
         """12 x OmniWhisperTransformerLayer (modules.py:214-232). h: [B*T, D] f32 residual stream (updated in place)."""
         D = h.shape[-1]
         M = B * T
+        fp8 = dt == ops.FP8_T
+        adt = torch.bfloat16 if fp8 else dt  # fp8 linears feed a bf16 attention
         for L in layers:
             x = ops.layernorm(h, L.ln1[0], L.ln1[1], 1e-5, B=B, t_in=T, C_=D, out_dtype=dt)
-            qkv = self._mm(x, L.wqkv, M, 3 * D, D, lda=D, bias=L.bqkv, out_dtype=dt)
+            qkv = self._mm(x, L.wqkv, M, 3 * D, D, lda=D, bias=L.bqkv, out_dtype=adt)
             a = ops.attention(qkv, lens, B, T, H)
+            if fp8:
+                a = ops.cast_fp8(a)
             self._mm(a, L.wo, M, D, D, lda=D, bias=L.bo, residual=h, out=h)
             x = ops.layernorm(h, L.ln2[0], L.ln2[1], 1e-5, B=B, t_in=T, C_=D, out_dtype=dt)
             F_ = L.b1.shape[0]
@@ -365,7 +379,7 @@ class AudioCodec(nn.Module):
                       t_out=Tm, out_dtype=dt)
         h = self._mm(c1, P.c2w, B * Ttok, D, D, lda=D, ldw=3 * D, bias=P.c2b, taps=3, stride=2, pad=1, t_in=Tm, t_out=Ttok)
         lens = self._dev_ints(tok_host, dev)
-        self._transformer(h, lens, B, Ttok, P.enc_layers, P.He, dt)
+        self._transformer(h, lens, B, Ttok, P.enc_layers, P.He, P.enc_ldt)
         s = P.stack
         tds_full = spec.cdiv(t_full, s)
         Tds = min(tds_full, spec.cdiv(Ttok, s) + 64)

@@ -12,6 +12,7 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short bf16_t;  // raw bf16 storage
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 struct f16s_t { unsigned short h; };  // tag type: split-f16 storage (see SWC_F16S in swc.h), addressed in halves
+struct fp8_t { unsigned char b; };    // OCP e4m3fn byte (SWC_FP8)
 
 void swc_set_error(const char* fmt, ...);
 
@@ -60,8 +61,20 @@ __device__ __forceinline__ void f16s_store4(unsigned short* row, long k, float a
     *reinterpret_cast<uint2*>(p + 32) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
 }
 
+// 4 floats -> 4 e4m3 bytes (v_cvt_pk_fp8_f32, RNE), saturating at the largest finite value
+__device__ __forceinline__ unsigned fp8_pack4(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f); d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return (unsigned)w;
+}
+
 template <typename T>
 __device__ __forceinline__ void store_out(T* p, float v);
+template <>
+__device__ __forceinline__ void store_out<fp8_t>(fp8_t* p, float v) { p->b = (unsigned char)(fp8_pack4(v, 0.f, 0.f, 0.f) & 0xff); }
 template <>
 __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <>

@@ -91,7 +91,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
     // ---- epilogue: lane (fr, fh) holds, for row 16i + fr, columns 16fh + 4j + e of its 64-column slab
     OutT* C = reinterpret_cast<OutT*>(p.C);
     const int col0 = bn + wc * 64 + 16 * fh;
-    const bool vec_ok = (col0 + 16 <= p.N) && ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0) &&
+    const bool vec_ok = (col0 + 16 <= p.N) && ((p.ldc & (sizeof(OutT) == 1 ? 15 : 3)) == 0) &&
+                        (!p.residual || (p.ldr & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
     float bv[16], gv[16];
@@ -111,7 +112,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float x = acc[i][j][e] * p.alpha + bv[4 * j + e];
-                if (p.act == SWC_ACT_GELU) x = __is_same(OutT, bf16_t) ? gelu_fast(x) : (__is_same(OutT, f16s_t) ? gelu_as(x) : gelu_erf(x));
+                if (p.act == SWC_ACT_GELU) x = (__is_same(OutT, bf16_t) || __is_same(OutT, fp8_t)) ? gelu_fast(x) : (__is_same(OutT, f16s_t) ? gelu_as(x) : gelu_erf(x));
                 v[4 * j + e] = x * gv[4 * j + e];
             }
         if constexpr (sizeof(OutT) == sizeof(f16s_t) && !__is_same(OutT, bf16_t)) {
@@ -155,6 +156,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     reinterpret_cast<float4*>(cp)[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+            } else if constexpr (sizeof(OutT) == 1) {
+                const float os = p.out_scale;
+                uint4 u;
+                u.x = fp8_pack4(v[0] * os, v[1] * os, v[2] * os, v[3] * os);
+                u.y = fp8_pack4(v[4] * os, v[5] * os, v[6] * os, v[7] * os);
+                u.z = fp8_pack4(v[8] * os, v[9] * os, v[10] * os, v[11] * os);
+                u.w = fp8_pack4(v[12] * os, v[13] * os, v[14] * os, v[15] * os);
+                *reinterpret_cast<uint4*>(cp) = u;
             } else {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -173,6 +182,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
                 if (col >= p.N) continue;
                 float x = v[c];
                 if (p.residual) x += p.residual[(long)row * p.ldr + col];
+                if constexpr (__is_same(OutT, fp8_t)) x *= p.out_scale;
                 if constexpr (!__is_same(OutT, f16s_t)) store_out<OutT>(C + (long)row * p.ldc + col, x);
             }
         }
@@ -189,7 +199,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     static_assert(RB == 128 || (RB == 64 && MODE != SWC_F16S), "split-f16 needs hi|lo in one 128-byte row");
     constexpr bool BF16 = MODE == SWC_BF16;
     constexpr bool F16S = MODE == SWC_F16S;
-    constexpr int ES = BF16 ? 2 : 4;    // bytes per LOGICAL element (split-f16 is 2 halves = 4 bytes)
+    constexpr bool FP8 = MODE == SWC_FP8;
+    constexpr int ES = BF16 ? 2 : (FP8 ? 1 : 4);  // bytes per LOGICAL element (split-f16 is 2 halves = 4 bytes)
     constexpr int EPC = 16 / ES;        // logical elements per 16-byte chunk (K-tail predicate only)
     constexpr int BK = ROW_BYTES / ES;  // logical elements of K per slice
     constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -406,6 +417,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             *reinterpret_cast<bf16x8*>(&fb[j]), *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
+            } else if constexpr (FP8) {
+                // a 16-byte chunk is 16 e4m3 k-values: its low and high 8 bytes feed two 16x16x32 steps (the k order
+                // inside the slice is permuted identically for both operands)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(reinterpret_cast<const long*>(&fb[j])[0],
+                                                                        reinterpret_cast<const long*>(&fa[i])[0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(reinterpret_cast<const long*>(&fb[j])[1],
+                                                                        reinterpret_cast<const long*>(&fa[i])[1], c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -447,7 +472,7 @@ int launch_k(GemmP p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * 64;
     constexpr int LDS = 2 * (BM + BN) * RB;
     {
-        constexpr int BK = RB / (MODE == SWC_BF16 ? 2 : 4);
+        constexpr int BK = RB / (MODE == SWC_BF16 ? 2 : (MODE == SWC_FP8 ? 1 : 4));
         p.kc_per_tap = (p.K + BK - 1) / BK;
     }
     p.n_tiles_n = (p.N + BN - 1) / BN;
@@ -486,8 +511,8 @@ int launch_k(GemmP p, hipStream_t s) {
 
 template <int MODE, typename OutT, int MT, int WM, int WN, int RB = 128>
 int launch(GemmP p, hipStream_t s) {
-    constexpr int BK = RB / (MODE == SWC_BF16 ? 2 : 4);
-    const long es = MODE == SWC_BF16 ? 2 : 4;
+    constexpr int BK = RB / (MODE == SWC_BF16 ? 2 : (MODE == SWC_FP8 ? 1 : 4));
+    const long es = MODE == SWC_BF16 ? 2 : (MODE == SWC_FP8 ? 1 : 4);
     const bool plain = (p.taps == 1) && (p.K % BK == 0) && (p.stride == 1) && (p.pad == 0) && (p.t_in == p.t_out) &&
                        p.lda * es < (1L << 24) && p.ldw * es < (1L << 24);  // 24-bit row pitch: offsets by v_mul_u32_u24
     return plain ? launch_k<MODE, OutT, MT, WM, WN, true, RB>(p, s) : launch_k<MODE, OutT, MT, WM, WN, false, RB>(p, s);
@@ -509,14 +534,19 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     SWC_CHECK_ARG(a != nullptr, "swc_gemm: null args");
     SWC_CHECK_ARG(a->A && a->W && a->C, "swc_gemm: null operand");
     SWC_CHECK_ARG(a->M >= 0 && a->N > 0 && a->K > 0, "swc_gemm: bad M/N/K %d %d %d", a->M, a->N, a->K);
-    SWC_CHECK_ARG(a->a_dtype == SWC_F32 || a->a_dtype == SWC_BF16 || a->a_dtype == SWC_F16S, "swc_gemm: bad a_dtype");
-    SWC_CHECK_ARG(a->c_dtype == SWC_F32 || a->c_dtype == SWC_BF16 || a->c_dtype == SWC_F16S, "swc_gemm: bad c_dtype");
+    SWC_CHECK_ARG(a->a_dtype == SWC_F32 || a->a_dtype == SWC_BF16 || a->a_dtype == SWC_F16S || a->a_dtype == SWC_FP8,
+                  "swc_gemm: bad a_dtype");
+    SWC_CHECK_ARG(a->c_dtype == SWC_F32 || a->c_dtype == SWC_BF16 || a->c_dtype == SWC_F16S ||
+                      (a->c_dtype == SWC_FP8 && a->a_dtype == SWC_FP8),
+                  "swc_gemm: bad c_dtype (FP8 outputs come from FP8 operands only)");
+    SWC_CHECK_ARG(a->c_dtype != SWC_F16S || a->a_dtype != SWC_FP8, "swc_gemm: fp8 operands have no split-f16 output");
     SWC_CHECK_ARG(a->c_dtype != SWC_F16S || (a->N % 32 == 0 && a->ldc % 32 == 0 && aligned16(a->C)),
                   "swc_gemm: split-f16 output needs N, ldc multiples of 32 (N=%d)", a->N);
     SWC_CHECK_ARG(a->act == SWC_ACT_NONE || a->act == SWC_ACT_GELU, "swc_gemm: bad act");
     const bool bf = a->a_dtype == SWC_BF16;
     const bool fs = a->a_dtype == SWC_F16S;
-    const int epc = bf ? 8 : (fs ? 32 : 4);
+    const bool f8 = a->a_dtype == SWC_FP8;
+    const int epc = bf ? 8 : (fs ? 32 : (f8 ? 16 : 4));
     SWC_CHECK_ARG(a->K % epc == 0, "swc_gemm: K=%d not a multiple of %d", a->K, epc);
     SWC_CHECK_ARG(a->lda % epc == 0 && a->ldw % epc == 0, "swc_gemm: lda/ldw break 16-byte rows");
     SWC_CHECK_ARG(aligned16(a->A) && aligned16(a->W), "swc_gemm: A/W not 16-byte aligned");
@@ -542,7 +572,7 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     p.act = a->act;
     p.alpha = a->alpha == 0.0f ? 1.0f : a->alpha;
     p.out_scale = a->out_scale == 0.0f ? 1.0f : a->out_scale;
-    const int bk = bf ? 64 : 32;
+    const int bk = bf ? 64 : (f8 ? 128 : 32);
     p.kc_per_tap = (a->K + bk - 1) / bk;
     p.n_tiles_n = p.n_tiles_m = 0;
     {
@@ -553,9 +583,9 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     // geometry: the 256x256 / 8-wave tile pays off when its grid still fills the 256 CUs
     const long big_tiles = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
-    bool big = bf && a->N >= 256 && big_tiles >= 96;
+    bool big = (bf || f8) && a->N >= 256 && big_tiles >= 96;
     if (tile_override() == 128) big = false;
-    if (tile_override() == 256) big = bf;
+    if (tile_override() == 256) big = bf || f8;
     int rc;
     const int cd = a->c_dtype;
 #define SWC_LAUNCH(MODE, MT, WM, WN)                                                        \
@@ -565,7 +595,7 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     // quantises best over the 256 CUs.  cost ~ rounds x (rows + fixed per-tile overhead); e.g. M = 16000, N = 768:
     // 189 tiles of 256 rows leave a quarter of the chip idle, 252 tiles of 192 rows fill it in one round.
     int mt = 8;
-    if ((bf && big) || (fs && a->N >= 256 && big_tiles >= 96)) {
+    if (((bf || f8) && big) || (fs && a->N >= 256 && big_tiles >= 96)) {
         static int forced = -1;
         if (forced < 0) forced = getenv("SWC_GEMM_MT") ? atoi(getenv("SWC_GEMM_MT")) : 0;
         const long ntn = (a->N + 255) / 256;
@@ -577,7 +607,16 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
         }
         if (forced == 8 || forced == 6 || forced == 4) mt = forced;
     }
-    if (bf) {
+    if (f8) {
+#define SWC_LAUNCH8(MT, WM, WN)                                                   \
+    (cd == SWC_BF16 ? launch<SWC_FP8, bf16_t, MT, WM, WN>(p, s)                     \
+                    : (cd == SWC_FP8 ? launch<SWC_FP8, fp8_t, MT, WM, WN>(p, s) : launch<SWC_FP8, float, MT, WM, WN>(p, s)))
+        if (big)
+            rc = mt == 8 ? SWC_LAUNCH8(8, 2, 4) : (mt == 6 ? SWC_LAUNCH8(6, 2, 4) : SWC_LAUNCH8(4, 2, 4));
+        else
+            rc = SWC_LAUNCH8(4, 2, 2);
+#undef SWC_LAUNCH8
+    } else if (bf) {
         if (big)
             rc = mt == 8 ? SWC_LAUNCH(SWC_BF16, 8, 2, 4) : (mt == 6 ? SWC_LAUNCH(SWC_BF16, 6, 2, 4) : SWC_LAUNCH(SWC_BF16, 4, 2, 4));
         else

@@ -41,7 +41,10 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, floa
 // (split-f16 rows are addressed in halves: 2 per logical column)
 template <typename OutT>
 __device__ __forceinline__ void store_row4(OutT* row, int col, float a, float b, float c, float d) {
-    if constexpr (__is_same(OutT, f16s_t)) {
+    if constexpr (__is_same(OutT, fp8_t)) {
+        *reinterpret_cast<unsigned*>(row + col) = fp8_pack4(a * SWC_FP8_ACT_SCALE, b * SWC_FP8_ACT_SCALE,
+                                                            c * SWC_FP8_ACT_SCALE, d * SWC_FP8_ACT_SCALE);
+    } else if constexpr (__is_same(OutT, f16s_t)) {
         f16s_store4(reinterpret_cast<unsigned short*>(row), col, a * SWC_F16S_ACT_SCALE, b * SWC_F16S_ACT_SCALE,
                     c * SWC_F16S_ACT_SCALE, d * SWC_F16S_ACT_SCALE);
     } else {
@@ -568,6 +571,22 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict
     if (i < n) y[i] = f32_to_bf16(x[i]);
 }
 
+template <typename InT>
+__global__ void cast_fp8_kernel(const InT* __restrict__ x, unsigned* __restrict__ y, long n4, float scale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 4 elements
+    if (i >= n4) return;
+    float a, b, c, d;
+    if constexpr (sizeof(InT) == 4) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        a = v.x; b = v.y; c = v.z; d = v.w;
+    } else {
+        const uint2 v = reinterpret_cast<const uint2*>(x)[i];
+        a = bf16_to_f32((bf16_t)(v.x & 0xffff)); b = bf16_to_f32((bf16_t)(v.x >> 16));
+        c = bf16_to_f32((bf16_t)(v.y & 0xffff)); d = bf16_to_f32((bf16_t)(v.y >> 16));
+    }
+    y[i] = fp8_pack4(a * scale, b * scale, c * scale, d * scale);
+}
+
 __global__ void cast_f16s_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ y, long rows,
                                  int K, float scale) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 4 logical columns
@@ -597,12 +616,19 @@ extern "C" int swc_layernorm(const float* x, void* y, const float* w, const floa
                              void* stream) {
     SWC_CHECK_ARG(x && y && w && b, "swc_layernorm: null pointer");
     SWC_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * LN_MAXV, "swc_layernorm: C=%d unsupported", C);
-    SWC_CHECK_ARG(y_dtype == SWC_F32 || y_dtype == SWC_BF16 || y_dtype == SWC_F16S, "swc_layernorm: bad dtype");
+    SWC_CHECK_ARG(y_dtype == SWC_F32 || y_dtype == SWC_BF16 || y_dtype == SWC_F16S || y_dtype == SWC_FP8,
+                  "swc_layernorm: bad dtype");
     SWC_CHECK_ARG(y_dtype != SWC_F16S || C % 32 == 0, "swc_layernorm: split-f16 output needs C % 32 == 0");
     const int tw = t_in < t_out ? t_in : t_out;
     const long rows = (long)B * tw;
     if (rows <= 0) return SWC_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (y_dtype == SWC_FP8) {
+        hipLaunchKernelGGL(layernorm_kernel<fp8_t>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (fp8_t*)y, w, b, lens, rows,
+                           tw, t_in, t_out, C, eps);
+        SWC_CHECK_LAUNCH("swc_layernorm");
+        return SWC_OK;
+    }
     OUT_DISPATCH3(y_dtype,
                   hipLaunchKernelGGL(layernorm_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (float*)y, w,
                                      b, lens, rows, tw, t_in, t_out, C, eps),
@@ -835,6 +861,24 @@ extern "C" int swc_cast_f32_bf16(const float* x, void* y, int64_t n, void* strea
     hipLaunchKernelGGL(cast_bf16_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y,
                        (long)n);
     SWC_CHECK_LAUNCH("swc_cast_f32_bf16");
+    return SWC_OK;
+}
+
+extern "C" int swc_cast_fp8(const void* x, int32_t x_dtype, void* y, int64_t n, float scale, void* stream) {
+    SWC_CHECK_ARG(x && y, "swc_cast_fp8: null pointer");
+    SWC_CHECK_ARG(x_dtype == SWC_F32 || x_dtype == SWC_BF16, "swc_cast_fp8: bad x_dtype");
+    SWC_CHECK_ARG(n >= 0 && n % 4 == 0, "swc_cast_fp8: n=%ld not a multiple of 4", (long)n);
+    SWC_CHECK_ARG((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 3) == 0,
+                  "swc_cast_fp8: unaligned");
+    if (n == 0) return SWC_OK;
+    const long n4 = n / 4;
+    if (x_dtype == SWC_F32)
+        hipLaunchKernelGGL(cast_fp8_kernel<float>, dim3(nblk(n4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)x, (unsigned*)y, n4, scale);
+    else
+        hipLaunchKernelGGL(cast_fp8_kernel<bf16_t>, dim3(nblk(n4, 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const bf16_t*)x, (unsigned*)y, n4, scale);
+    SWC_CHECK_LAUNCH("swc_cast_fp8");
     return SWC_OK;
 }
 

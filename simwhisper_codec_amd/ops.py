@@ -8,10 +8,12 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, BF16, F16S, F16S_ACT_SCALE, F32  # noqa: F401
+from ._lib import ACT_GELU, ACT_NONE, BF16, F16S, F16S_ACT_SCALE, F32, FP8, FP8_ACT_SCALE  # noqa: F401
 
 # torch.float16 tensors carry the split-f16 format (SWC_F16S): last dim = 2 x logical columns
-_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16S}
+# torch.float8_e4m3fn tensors carry SWC_FP8 bytes (OCP e4m3fn, gfx950's native fp8)
+FP8_T = torch.float8_e4m3fn
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16S, FP8_T: FP8}
 
 
 def _w(dtype, cols):
@@ -74,7 +76,7 @@ def gemm(A, W, M, N, K, *, out=None, out_dtype=None, lda=None, ldw=None, ldc=Non
     a.alpha, a.out_scale = alpha, out_scale
     prof = PROFILER
     if prof is not None:
-        prof.begin({torch.bfloat16: "gemm_bf16", torch.float16: "gemm_f16s"}.get(A.dtype, "gemm_f32"),
+        prof.begin({torch.bfloat16: "gemm_bf16", torch.float16: "gemm_f16s", FP8_T: "gemm_fp8"}.get(A.dtype, "gemm_f32"),
                    2.0 * M * N * K * taps)
     _lib.check(lib.swc_gemm(C.byref(a), _stream()), "swc_gemm")
     if prof is not None:
@@ -213,6 +215,18 @@ def cast_bf16(x):
     x = x.contiguous()
     y = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
     _lib.check(lib.swc_cast_f32_bf16(_ptr(x), _ptr(y), x.numel(), _stream()), "swc_cast_f32_bf16")
+    return y
+
+
+def cast_fp8(x, scale=FP8_ACT_SCALE):
+    """f32 / bf16 tensor * scale -> e4m3 bytes (torch.float8_e4m3fn storage), saturating."""
+    lib = _lib.load()
+    _chk(x, "cast_fp8 x")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.SwcError(f"cast_fp8: expected f32 or bf16, got {x.dtype}")
+    x = x.contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=FP8_T)
+    _lib.check(lib.swc_cast_fp8(_ptr(x), _DT[x.dtype], _ptr(y), x.numel(), scale, _stream()), "swc_cast_fp8")
     return y
 
 

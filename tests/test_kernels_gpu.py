@@ -511,3 +511,71 @@ def test_code_bitstream(tmp_path):
     bitstream.write_codes(str(p), codes.to(DEV))
     assert p.stat().st_size == 12 + 11 * 1000  # 1100 bit/s + 12-byte header
     assert torch.equal(bitstream.read_codes(str(p)).cpu(), codes)
+
+
+# ----------------------------------------------------------------- fp8 (OCP e4m3fn) preset kernels
+def _fp8_to_f64(t):
+    return t.cpu().float().double()
+
+
+def test_cast_fp8_matches_torch():
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(64, 256, generator=g) * 3.0
+    x[0, :8] = torch.tensor([0.0, -0.0, 447.9 / 16, 448.0 / 16, 1e-4, -1e-4, 0.0019, 27.99])
+    want = (x * 16.0).to(torch.float8_e4m3fn)  # in range: torch's RNE cast is the reference
+    got = ops.cast_fp8(x.to(DEV), 16.0)
+    assert got.dtype == torch.float8_e4m3fn
+    assert torch.equal(got.cpu().view(torch.uint8), want.view(torch.uint8))
+    got_b = ops.cast_fp8(x.to(torch.bfloat16).to(DEV), 16.0)
+    want_b = (x.to(torch.bfloat16).float() * 16.0).to(torch.float8_e4m3fn)
+    assert torch.equal(got_b.cpu().view(torch.uint8), want_b.view(torch.uint8))
+    # saturation instead of NaN / inf
+    big = torch.tensor([1e6, -1e6, 500.0, -449.0], device=DEV)
+    sat = ops.cast_fp8(big, 1.0).cpu().float()
+    assert sat.tolist() == [448.0, -448.0, 448.0, -448.0]
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 256), (1000, 768, 768), (257, 96, 3072), (130, 64, 144), (4096, 3072, 768)])
+def test_gemm_fp8(M, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) * 0.03
+    bias = torch.randn(N, generator=g)
+    sa, sw = 16.0, 2.0 ** 11
+    A8, W8 = ops.cast_fp8(A.to(DEV), sa), ops.cast_fp8(W.to(DEV), sw)
+    # the kernel must reproduce the product of the QUANTISED operands; the fp8 MFMA's internal sum is a little
+    # coarser than an f32 fma chain (measured 1.2e-5 of the output range), four orders below the e4m3 step
+    ref = (_fp8_to_f64(A8) / sa) @ (_fp8_to_f64(W8) / sw).T + bias.double()
+    out = ops.gemm(A8, W8, M, N, K, bias=bias.to(DEV), alpha=1.0 / (sa * sw))
+    assert _rel(out, ref) < 5e-5
+    res = torch.randn(M, N, generator=g)
+    o_bf = ops.gemm(A8, W8, M, N, K, bias=bias.to(DEV), alpha=1.0 / (sa * sw), out_dtype=torch.bfloat16)
+    assert _rel(o_bf.float(), ref) < 8e-3
+    o_res = ops.gemm(A8, W8, M, N, K, bias=bias.to(DEV), alpha=1.0 / (sa * sw), residual=res.to(DEV))
+    assert _rel(o_res, ref + res.double()) < 5e-5
+    if N % 16 == 0:
+        o8 = ops.gemm(A8, W8, M, N, K, bias=bias.to(DEV), alpha=1.0 / (sa * sw), act=ops.ACT_GELU,
+                      out_dtype=torch.float8_e4m3fn, out_scale=16.0)
+        want = torch.nn.functional.gelu(ref)
+        got = _fp8_to_f64(o8) / 16.0
+        # e4m3: 3 mantissa bits -> half an ulp is 2^-4 relative; subnormal step 2^-9 / 16
+        tol = want.abs() * 2.0 ** -4 + 2.0 ** -9 / 16 + 1e-3
+        assert bool(((got - want).abs() <= tol).all())
+    # the quantisation itself: fp8 operands carry ~2^-4 relative error per element
+    full = A.double() @ W.double().T + bias.double()
+    assert _rel(out, full) < 0.1
+
+
+def test_layernorm_fp8_out():
+    ops = _ops()
+    B, T, C = 2, 37, 768
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, T, C, generator=g) * 2 + 0.3
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    out = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, B=B, t_in=T, C_=C, out_dtype=torch.float8_e4m3fn)
+    want = F.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-5)
+    got = _fp8_to_f64(out) / 16.0
+    tol = want.abs() * 2.0 ** -4 + 2.0 ** -9 / 16 + 1e-5
+    assert bool(((got - want).abs() <= tol).all())

@@ -138,6 +138,45 @@ def test_vs_oracle_fresh_input():
         assert _relerr(a.cpu().numpy(), b.numpy()) < TOL_FP32
 
 
+# Reduced-precision encoder presets (BASELINE.json configs[1] "bf16", configs[4] "fp8 encoder GEMMs"): indices can no
+# longer be bit-exact, so the tolerance is re-stated on the FSQ levels themselves.  A code packs 4 levels
+# (8, 7, 6, 6 steps); a flipped level is a latent that sat near a rounding boundary.  Floors sit a few points under the
+# values measured on MI355X with the synthetic checkpoint (real config, 8 x 5 s fresh utterances):
+#   bf16: 98.7 % of levels equal (95.1 % of codes), none off by more than 1;   fp8: 87.0 % equal (58 % of codes), 99.8 % within 1.
+LEVEL_FLOORS = {"bf16": (0.97, 0.9995), "fp8": (0.84, 0.995)}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_reduced_precision_encoder_levels(precision):
+    from simwhisper_codec_amd import synth
+    tag = "real"
+    wavs = [synth.synth_audio(80000 - 331 * i, index=700 + i, kind="speech" if i % 2 else "noise") for i in range(8)]
+    o = oracle(tag)
+    want = o.encode(wavs, trim=True)["codes_list"]
+    m = model(tag, precision)
+    got = m.encode([w.to(DEV) for w in wavs])["codes_list"]
+    base = torch.tensor([1, 8, 56, 336])
+    lev = torch.tensor([8, 7, 6, 6])
+    same = within1 = total = codes_same = codes_total = 0
+    for a, b in zip(got, want):
+        a, b = a.cpu().long(), b.long()
+        assert a.shape == b.shape
+        la = (a[..., None] // base) % lev
+        lb = (b[..., None] // base) % lev
+        d = (la - lb).abs()
+        same += int((d == 0).sum()); within1 += int((d <= 1).sum()); total += d.numel()
+        codes_same += int((a == b).sum()); codes_total += a.numel()
+    _report(f"levels/{precision}", equal=same / total, within1=within1 / total, codes_equal=codes_same / codes_total)
+    lo_eq, lo_w1 = LEVEL_FLOORS[precision]
+    assert same / total >= lo_eq, (same / total, within1 / total)
+    assert within1 / total >= lo_w1, (same / total, within1 / total)
+    # the decoder is the bf16 one in both presets: identical codes in, waveform within the bf16 tolerance
+    wr = o.decode(want)["syn_wav_list"]
+    wg = m.decode([c.to(DEV) for c in want])["syn_wav_list"]
+    for x, y in zip(wg, wr):
+        assert _relerr(x.cpu().numpy(), y.numpy()) < TOL_BF16
+
+
 def test_no_cpu_fallback():
     from simwhisper_codec_amd.codec import AudioCodec
     from simwhisper_codec_amd._lib import SwcError
