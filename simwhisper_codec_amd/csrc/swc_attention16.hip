@@ -136,7 +136,19 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-    const float s_scale = PLANES == 1 ? 1.0f : 1.0f / (SWC_F16S_ACT_SCALE * SWC_F16S_ACT_SCALE);
+    // bf16 path: scores are kept in the log2 domain (scale folded with log2 e), one v_exp_f32 per element.
+    // split-f16 path (indices must stay bit-exact): natural domain and exp_c below — v_exp_f32 on a compensated
+    // argument (the rounding of t * log2 e is fed back through a first-order term), ~1 ulp like libm's expf at a
+    // third of its instructions; the plain log2-domain form flipped one index in the 10 k of a parity test.
+    const float s_scale = PLANES == 1 ? 1.4426950408889634f : 1.0f / (SWC_F16S_ACT_SCALE * SWC_F16S_ACT_SCALE);
+    auto exp_c = [](float t) -> float {
+        t = fmaxf(t, -100.0f);                                   // masked keys / first tile arrive as -inf: e^-100 == 0 here
+        const float y = t * 1.4426950216293335f;                 // float(log2 e)
+        float r = fmaf(t, 1.4426950216293335f, -y);              // exact rounding error of the product
+        r = fmaf(t, 1.9259629911266175e-8f, r);                  // + t * (log2 e - float(log2 e))
+        const float e = __builtin_amdgcn_exp2f(y);
+        return fmaf(e, r * 0.6931471805599453f, e);              // 2^(y + r) ~= 2^y (1 + r ln 2)
+    };
     constexpr float P_SCALE = 2048.0f;  // split-f16 P: keeps the lo halves of small probabilities normal
 
     const int ntile = (len + KT16 - 1) / KT16;
@@ -194,14 +206,14 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
             mt = fmaxf(mt, __shfl_xor(mt, 16));
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float m_new = fmaxf(m_run[qt], mt);
-            const float alpha = PLANES == 1 ? __expf(m_run[qt] - m_new) : expf(m_run[qt] - m_new);
+            const float alpha = PLANES == 1 ? __builtin_amdgcn_exp2f(m_run[qt] - m_new) : exp_c(m_run[qt] - m_new);
             m_run[qt] = m_new;
             float psum = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pv = PLANES == 1 ? __expf(s[qt][ks][e] - m_new) : expf(s[qt][ks][e] - m_new);
+                    const float pv = PLANES == 1 ? __builtin_amdgcn_exp2f(s[qt][ks][e] - m_new) : exp_c(s[qt][ks][e] - m_new);
                     s[qt][ks][e] = pv;
                     psum += pv;
                 }
