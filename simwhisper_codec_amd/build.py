@@ -14,6 +14,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libswc_hip.so")
 SOURCES = ["swc_api.hip", "swc_gemm.hip", "swc_attention.hip", "swc_attention16.hip", "swc_pointwise.hip"]
 ARCH = "gfx950"
+# per-file flags.  -fno-slp-vectorize: hipcc otherwise packs adjacent f32 mul/add/fma into v_pk_*_f32, which issue at
+# half rate on gfx950 and cost extra v_mov shuffles — slower beside MFMAs (softmax, epilogues)
+EXTRA_FLAGS = {"swc_attention16.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -47,7 +50,7 @@ def build_library(force=False, verbose=False):
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = common + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = common + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

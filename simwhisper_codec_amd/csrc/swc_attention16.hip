@@ -14,6 +14,7 @@
 // V^T operand (4 consecutive keys of one channel) comes out of the row-major V tile through
 // ds_read_b64_tr_b16, the hardware transposing read.
 #include "swc_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -136,27 +137,25 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-    // bf16 path: scores are kept in the log2 domain (scale folded with log2 e), one v_exp_f32 per element.
-    // split-f16 path (indices must stay bit-exact): natural domain and exp_c below — v_exp_f32 on a compensated
-    // argument (the rounding of t * log2 e is fed back through a first-order term), ~1 ulp like libm's expf at a
-    // third of its instructions; the plain log2-domain form flipped one index in the 10 k of a parity test.
-    const float s_scale = PLANES == 1 ? 1.4426950408889634f : 1.0f / (SWC_F16S_ACT_SCALE * SWC_F16S_ACT_SCALE);
-    auto exp_c = [](float t) -> float {
-        t = fmaxf(t, -100.0f);                                   // masked keys / first tile arrive as -inf: e^-100 == 0 here
-        const float y = t * 1.4426950216293335f;                 // float(log2 e)
-        float r = fmaf(t, 1.4426950216293335f, -y);              // exact rounding error of the product
-        r = fmaf(t, 1.9259629911266175e-8f, r);                  // + t * (log2 e - float(log2 e))
-        const float e = __builtin_amdgcn_exp2f(y);
-        return fmaf(e, r * 0.6931471805599453f, e);              // 2^(y + r) ~= 2^y (1 + r ln 2)
-    };
-    constexpr float P_SCALE = 2048.0f;  // split-f16 P: keeps the lo halves of small probabilities normal
+    // Softmax exponentials: raw scores (split-f16: still carrying the operand scales 64 * 64), running maximum in
+    // the same raw units, and p = 2^((s - m) * c) with c = scale * log2 e.  The subtraction comes FIRST: it is exact
+    // (or rounds at the size of the difference), so the only new error is the rounding of the product, relative
+    // |y| 2^-24 ln 2 in p — at most 2e-8 once weighted by p itself, the size of an f32 rounding.  (Scaling before
+    // the subtraction rounds at the size of the score instead and did flip an index in a parity test.)  One
+    // v_exp_f32 per element instead of libm's expf; masked keys give 2^-inf = 0.
+    // split-f16: P is produced directly at its operand scale 2048 (lo halves of small probabilities stay normal)
+    // by lowering the subtracted maximum by log2(2048) / c; the row sum carries the same factor and cancels it.
+    const float c_exp = (PLANES == 1 ? 1.0f : 1.0f / (SWC_F16S_ACT_SCALE * SWC_F16S_ACT_SCALE)) * 1.4426950408889634f;
+    const float m_off = PLANES == 1 ? 0.0f : 11.0f / c_exp;
 
     const int ntile = (len + KT16 - 1) / KT16;
     stage(0, 0);
     fence();
-    for (int kt = 0; kt < ntile; ++kt) {
+    // one key tile; LAST: the tile may hold keys >= len (masking and the -inf guards are compiled only there)
+    auto tile = [&](int kt, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
         const int st = kt & 1;
-        if (kt + 1 < ntile) stage(kt + 1, st ^ 1);
+        if (!LAST) stage(kt + 1, st ^ 1);
         const char* sK = smem + st * 2 * TILE;
         const char* sV = sK + TILE;
         const int k0 = kt * KT16;
@@ -198,22 +197,23 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int key = k0 + ks * 16 + fh * 4 + e;
-                    float v = s[qt][ks][e] * s_scale;
-                    v = key < len ? v : -INFINITY;
+                    float v = s[qt][ks][e];
+                    if (LAST) v = key < len ? v : -INFINITY;
                     s[qt][ks][e] = v;
                     mt = fmaxf(mt, v);
                 }
             mt = fmaxf(mt, __shfl_xor(mt, 16));
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float m_new = fmaxf(m_run[qt], mt);
-            const float alpha = PLANES == 1 ? __builtin_amdgcn_exp2f(m_run[qt] - m_new) : exp_c(m_run[qt] - m_new);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c_exp);
             m_run[qt] = m_new;
+            const float m_sub = m_new - m_off;
             float psum = 0.f;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pv = PLANES == 1 ? __builtin_amdgcn_exp2f(s[qt][ks][e] - m_new) : exp_c(s[qt][ks][e] - m_new);
+                    const float pv = __builtin_amdgcn_exp2f((s[qt][ks][e] - m_sub) * c_exp);
                     s[qt][ks][e] = pv;
                     psum += pv;
                 }
@@ -229,7 +229,12 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
                     if constexpr (PLANES == 1) {
                         h[j] = f32_to_bf16(pv);
                     } else {
-                        f16s_split(pv * P_SCALE, h[j], lo[j]);
+                        // p * 2048 <= 2048: no saturation clamp needed here
+                        const float ps = pv;
+                        const _Float16 hh = (_Float16)ps;
+                        const _Float16 ll = (_Float16)(ps - (float)hh);
+                        h[j] = *reinterpret_cast<const unsigned short*>(&hh);
+                        lo[j] = *reinterpret_cast<const unsigned short*>(&ll);
                     }
                 }
                 pf[qt][pr][0] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16),
@@ -272,7 +277,9 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
                 }
             }
         fence();
-    }
+    };
+    for (int kt = 0; kt + 1 < ntile; ++kt) tile(kt, std::false_type{});
+    tile(ntile - 1, std::true_type{});
 
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
         l += __shfl_xor(l, 16);
         l += __shfl_xor(l, 32);
         // split-f16: acc = sum (P * 2048) (V * 64); the output is written at the activation scale 64
-        const float inv = l > 0.f ? (PLANES == 1 ? 1.0f / l : 1.0f / (P_SCALE * l)) : 0.f;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;  // split-f16: P and its row sum both carry the factor 2048
         const int q = q0 + wave * 32 + qt * 16 + fr;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
