@@ -107,7 +107,10 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # one process per GPU over RCCL; also initialised for a single rank launched by torch.distributed.run, so that the
+    # N > 1 code path (init, barrier, MAX all-reduce) can be exercised on a one-GPU box
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -129,7 +132,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -147,7 +150,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     assert len(out["syn_wav_list"]) == args.batch and out["syn_wav_list"][0].shape[0] == (n // 1280) * 1280
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -188,7 +191,7 @@ def main():
             threads = min(16, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(gp, sd, args.cpu_utts, args.seconds, threads)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
