@@ -577,8 +577,8 @@ class AudioCodec(nn.Module):
         dev = self._buffers_device() if device is None else torch.device(device)
         if L == 0:
             return {"syn_wav_list": [torch.zeros(0, device=dev) for _ in range(B)]}
-        if len(set(n)) == 1 and n[0] == L and all(c.device == dev for c in codes_list):
-            codes = torch.stack([c.to(torch.long) for c in codes_list], dim=1)
+        if len(set(n)) == 1 and n[0] == L and all(c.device == dev and c.dtype == codes_list[0].dtype for c in codes_list):
+            codes = torch.stack(list(codes_list), dim=1).to(torch.long)  # one conversion, not one per utterance
         else:
             codes = torch.zeros(self.num_groups, B, L, device=dev, dtype=torch.long)
             for i, c in enumerate(codes_list):
