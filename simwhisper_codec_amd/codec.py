@@ -391,8 +391,14 @@ class AudioCodec(nn.Module):
         z = self._mm(self._cast(hd, dt), P.tlw, B * Tds, P.lat, P.hid, lda=P.hid, bias=P.tlb)
         return z.view(B, Tds, P.lat), Tds, [spec.cdiv(t, s) for t in tok_host]
 
-    def _decode_latent(self, zq, lat_host, B, T, P):
-        """up-sampler + decoder + Vocos on zq [B, T, lat] f32 (already masked). Returns wav [B, T*1280] f32."""
+    # Vocos receptive field: embed k7 (+-3) + 24 depthwise k7 (+-72) frames, ISTFT overlap +-2 frames (SURVEY.md 8a row V
+    # measured -73 ... +74): frames computed this far beyond the kept ones make the kept samples bit-identical
+    VOCOS_HALO_FRAMES = 80
+
+    def _decode_latent(self, zq, lat_host, B, T, P, keep_frames=None):
+        """up-sampler + decoder + Vocos on zq [B, T, lat] f32 (already masked). Returns wav [B, T*1280] f32, or
+        [B, keep_frames*160] when only the first keep_frames Vocos frames are wanted (long-form windows keep 2000
+        of their 3000 frames: the local-receptive-field vocoder then runs on 2000 + halo frames)."""
         dt, dev = P.ddt, zq.device
         s, D = P.stack, P.Dd
         h = self._mm(self._cast(zq, dt), P.flw, B * T, P.uhid, P.lat, lda=P.lat, bias=P.flb)
@@ -409,6 +415,9 @@ class AudioCodec(nn.Module):
         d1 = ops.deconv_col2im(y3, P.d1b, B=B, T=Tt, C_=D, s=2, t_out=Tv + 1, out_dtype=dt)
         mel = self._mm(d1, P.d2w, B * Tv, P.vin, D, lda=D, ldw=3 * D, bias=P.d2b, taps=3, pad=2, t_in=Tv + 1, t_out=Tv,
                        out_dtype=dt)
+        if keep_frames is not None and keep_frames < Tv:
+            mel = mel.view(B, Tv, -1)[:, :keep_frames].contiguous()
+            Tv = keep_frames
         return self._vocos(mel, B, Tv, P)
 
     def _vocos(self, mel, B, Tv, P):
@@ -487,20 +496,27 @@ class AudioCodec(nn.Module):
         return {"zq": zq.transpose(1, 2), "codes": codes, "codes_lengths": lat_dev.long()}
 
     @torch.inference_mode()
-    def inference_detokenize(self, codes, codes_lengths):
-        """model.py:212-242. codes (G, B, T) integer, codes_lengths (B,). Returns y (B, 1, T*1280), output_length."""
+    def inference_detokenize(self, codes, codes_lengths, _keep_samples=None):
+        """model.py:212-242. codes (G, B, T) integer, codes_lengths (B,). Returns y (B, 1, T*1280), output_length.
+        _keep_samples (internal, decode()): only the first _keep_samples samples of every row are needed; y is then
+        shorter than T*1280 but those samples are bit-identical."""
         P = self._packed()
         G, B, T = codes.shape
         lat = [int(v) for v in (codes_lengths.tolist() if torch.is_tensor(codes_lengths) else codes_lengths)]
         dev = codes.device
         lat_dev = self._dev_ints(lat, dev)
         zq = ops.fsq_decode(codes.to(torch.int64).contiguous(), lat_dev, B=B, T=T, G=G)
-        wav = self._decode_latent(zq, lat, B, T, P)
+        kf = None
+        if _keep_samples is not None:
+            hop = self.generator_params["vocos"]["hop_size"]
+            kf = spec.cdiv(_keep_samples, hop) + self.VOCOS_HALO_FRAMES
+        wav = self._decode_latent(zq, lat, B, T, P, keep_frames=kf)
         return {"y": wav[:, None, :], "output_length": lat_dev.long() * self.decoder_upsample_rate}
 
     # long-form scheduling: windows of one call are independent rows, so several 30 s windows are batched into
     # one tokenize / detokenize call (the reference loops them serially, model.py:275,340)
     max_rows_per_call = 64
+    trim_vocos = True  # decode(): run Vocos only on the kept frames (+ halo) of each window; bit-identical output
 
     @staticmethod
     def _stack(tensors, lens, dev, dtype):
@@ -604,7 +620,7 @@ class AudioCodec(nn.Module):
                 else:
                     cg = torch.cat([codes[:, :, s0:e0] for _, s0, e0, _ in grp], dim=1)
                     lens = [v for *_, cl in grp for v in cl]
-                y = self.inference_detokenize(cg, lens)["y"]
+                y = self.inference_detokenize(cg, lens, _keep_samples=keep if self.trim_vocos else None)["y"]
                 # samples beyond an utterance's valid length fall after its final trim (n_i * 1280), so the
                 # zero-fill of model.py:356-360 is unobservable: keep the first `keep` samples of each window
                 for k, wdw in enumerate(grp):

@@ -213,6 +213,27 @@ def test_window_batching_is_exact():
         assert torch.equal(a.cpu().long(), b.long())
 
 
+@pytest.mark.parametrize("tag,precision", [("tiny", "fp32"), ("real", "mixed")])
+def test_vocos_halo_trim_is_exact(tag, precision):
+    """decode() runs Vocos only on the kept 2000 frames (+80 halo) of a 3000-frame window: the
+    kept samples must be bit-identical to computing all 3000 frames as the reference does."""
+    from simwhisper_codec_amd import synth
+    m = model(tag, precision)
+    g = torch.Generator().manual_seed(11)
+    n_codes = [375 + 40, 375, 251]  # 2 windows (full + 165 codes), exactly one full window + tail, 250 + 1
+    codes = [torch.randint(0, 2016, (m.num_groups, n), generator=g).to(DEV) for n in n_codes]
+    try:
+        m.trim_vocos = False
+        full = m.decode(codes)["syn_wav_list"]
+        m.trim_vocos = True
+        trim = m.decode(codes)["syn_wav_list"]
+    finally:
+        m.trim_vocos = True
+    for a, b, n in zip(full, trim, n_codes):
+        assert a.shape == b.shape == (n * 1280,)
+        assert torch.equal(a, b)
+
+
 def test_api_edge_cases():
     """inputs on the host, empty members, single utterance, float64 audio: same answers as the oracle."""
     from simwhisper_codec_amd import synth
