@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--precision", default="mixed", choices=["fp32", "mixed", "mixed_f32", "bf16", "fp8"])
-    ap.add_argument("--cpu-utts", type=int, default=4, help="utterances in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-utts", type=int, default=8, help="utterances in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-gemm-timer", action="store_true")
     args = ap.parse_args()
 

@@ -23,21 +23,35 @@ import torch
 DEFAULT_SEED = 20251226
 
 
+def _uniform_chunk(out, lo, hi, s):
+    x = np.arange(lo, hi, dtype=np.uint64).astype(np.uint32)
+    x = x * np.uint32(0x9E3779B1) + s
+    x ^= x >> np.uint32(16)
+    x *= np.uint32(0x21F0AAAD)
+    x ^= x >> np.uint32(15)
+    x *= np.uint32(0x735A2D97)
+    x ^= x >> np.uint32(15)
+    out[lo:hi] = (x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -23) - np.float32(1.0)
+
+
+_POOL = None
+
+
 def _uniform(name, n, seed):
-    """n values in [-1, 1), element i = f(crc32(name), i, seed)."""
+    """n values in [-1, 1), element i = f(crc32(name), i, seed).  Large tensors are filled in 4 Mi-element chunks by
+    a small thread pool (numpy releases the GIL inside the ufuncs); the values do not depend on the chunking."""
+    global _POOL
     s = np.uint32((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0xFFFFFFFF)
     out = np.empty(n, dtype=np.float32)
-    step = 1 << 24
-    for lo in range(0, n, step):
-        hi = min(n, lo + step)
-        x = np.arange(lo, hi, dtype=np.uint64).astype(np.uint32)
-        x = x * np.uint32(0x9E3779B1) + s
-        x ^= x >> np.uint32(16)
-        x *= np.uint32(0x21F0AAAD)
-        x ^= x >> np.uint32(15)
-        x *= np.uint32(0x735A2D97)
-        x ^= x >> np.uint32(15)
-        out[lo:hi] = (x >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -23) - np.float32(1.0)
+    step = 1 << 22
+    if n <= step:
+        _uniform_chunk(out, 0, n, s)
+        return out
+    if _POOL is None:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1)))
+    list(_POOL.map(lambda lo: _uniform_chunk(out, lo, min(n, lo + step), s), range(0, n, step)))
     return out
 
 
