@@ -301,18 +301,7 @@ template <int PLANES>
 int launch16(const void* qkv, void* out, const int32_t* lens, int B, int T, int H, hipStream_t s) {
     constexpr int LDS = 2 * 2 * KT16 * 128 * PLANES;
     auto kern = attn16_kernel<PLANES>;
-    if (LDS > 48 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            if (e != hipSuccess) {
-                swc_set_error("swc_attention: cannot enable %d bytes of LDS: %s", LDS, hipGetErrorString(e));
-                return SWC_E_LAUNCH;
-            }
-            attr_set = true;
-        }
-    }
+    if (LDS > 48 * 1024) SWC_ENABLE_LDS(kern, LDS, "swc_attention16");
     dim3 grid((T + QB16 - 1) / QB16, H, B), block(256);
     hipLaunchKernelGGL(kern, grid, block, LDS, s, (const char*)qkv, (unsigned short*)out, lens, T, H);
     return SWC_OK;

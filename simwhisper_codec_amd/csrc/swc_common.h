@@ -111,4 +111,23 @@ __device__ __forceinline__ float gelu_as(float x) {
     return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// One-time (per kernel instantiation and per device) opt-in to more than 64 KiB of dynamic LDS.  `done` is a
+// per-call-site static array indexed by device; a race only repeats the idempotent attribute call.
+#define SWC_ENABLE_LDS(kern, bytes, who)                                                                    \
+    do {                                                                                                    \
+        static bool done__[64] = {};                                                                        \
+        int dev__ = 0;                                                                                      \
+        (void)hipGetDevice(&dev__);                                                                         \
+        const int slot__ = (dev__ >= 0 && dev__ < 64) ? dev__ : 0;                                          \
+        if (!done__[slot__] || dev__ >= 64) {                                                               \
+            hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                       \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (bytes));      \
+            if (e__ != hipSuccess) {                                                                        \
+                swc_set_error("%s: cannot enable %d bytes of LDS: %s", who, (int)(bytes), hipGetErrorString(e__)); \
+                return SWC_E_LAUNCH;                                                                        \
+            }                                                                                               \
+            done__[slot__] = true;                                                                          \
+        }                                                                                                   \
+    } while (0)
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -488,18 +488,7 @@ int launch_k(GemmP p, hipStream_t s) {
         return SWC_E_ARG;
     }
     auto kern = gemm_kernel<MODE, OutT, MT, WM, WN, PLAIN, RB>;
-    if (LDS > 64 * 1024) {
-        static bool attr_set = false;  // per instantiation; benign race (same value)
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-            if (e != hipSuccess) {
-                swc_set_error("swc_gemm: cannot enable %d bytes of LDS: %s", LDS, hipGetErrorString(e));
-                return SWC_E_LAUNCH;
-            }
-            attr_set = true;
-        }
-    }
+    if (LDS > 64 * 1024) SWC_ENABLE_LDS(kern, LDS, "swc_gemm");
     // persistent grid: one workgroup per CU for the 8-wave geometries, two for the 4-wave one (256 CUs)
     static int persist = -1;
     if (persist < 0) persist = getenv("SWC_GEMM_NOPERSIST") ? 0 : 1;

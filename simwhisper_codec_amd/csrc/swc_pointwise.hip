@@ -645,18 +645,7 @@ static int launch_dwconv7_ln(const float* x, void* y, const float* w, const floa
                              const float* ln_b, int B, int T, int C, float eps, hipStream_t s) {
     const int lds = (S + 6) * C * 4;
     auto kern = dwconv7_ln_kernel<OutT, NK, S, FULL>;
-    if (lds > 48 * 1024) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) {
-                swc_set_error("swc_dwconv7_ln: cannot enable %d bytes of LDS: %s", lds, hipGetErrorString(e));
-                return SWC_E_LAUNCH;
-            }
-            attr_set = true;
-        }
-    }
+    if (lds > 48 * 1024) SWC_ENABLE_LDS(kern, 160 * 1024, "swc_dwconv7_ln");
     const int nst = (T + S - 1) / S, nstrips = nst * B;
     // resident workgroups: LDS-limited per CU, 256 CUs; each walks nstrips / grid strips
     static const int wgs = getenv("SWC_DW_WGS") ? atoi(getenv("SWC_DW_WGS")) : 0;
