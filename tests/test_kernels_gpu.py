@@ -579,3 +579,53 @@ def test_layernorm_fp8_out():
     got = _fp8_to_f64(out) / 16.0
     tol = want.abs() * 2.0 ** -4 + 2.0 ** -9 / 16 + 1e-5
     assert bool(((got - want).abs() <= tol).all())
+
+
+def test_gemm_shape_fuzz():
+    """Random shapes / strides / epilogues through every operand type against a float64 product: edge tiles, the
+    PLAIN and implicit-conv stagings, persistent walks with fewer tiles than workgroups, padded leading dimensions."""
+    ops = _ops()
+    rng = np.random.default_rng(1234)
+    g = torch.Generator().manual_seed(99)
+    for it in range(48):
+        kind = ["f32", "bf16", "f16s", "fp8"][it % 4]
+        kmul = {"f32": 4, "bf16": 8, "f16s": 32, "fp8": 16}[kind]
+        M = int(rng.integers(1, 1400))
+        N = int(rng.integers(1, 700))
+        K = kmul * int(rng.integers(1, 40))
+        if it % 6 == 0:  # exercise the 8-wave geometries and the PLAIN path
+            M, N, K = int(rng.integers(2000, 9000)), 256 * int(rng.integers(1, 4)), 128 * int(rng.integers(1, 8))
+        pad = kmul * int(rng.integers(0, 3))
+        A = torch.randn(M, K + pad, generator=g)
+        W = torch.randn(N, K + pad, generator=g) * 0.05
+        bias = torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g) if it % 3 == 0 else None
+        gelu = it % 5 == 0
+        Ad, Wd = A.to(DEV), W.to(DEV)
+        if kind == "bf16":
+            Aq, Wq, alpha = Ad.to(torch.bfloat16), Wd.to(torch.bfloat16), 1.0
+            Ar, Wr = Aq.float().cpu().double(), Wq.float().cpu().double()
+            tol = 2e-5
+        elif kind == "f16s":
+            Aq = ops.cast_f16s(Ad[:, :K].contiguous(), K, scale=64.0)
+            Wq = ops.cast_f16s(Wd[:, :K].contiguous(), K, scale=2.0 ** 12)
+            alpha, Ar, Wr, tol, pad = 1.0 / (64.0 * 2.0 ** 12), A[:, :K].double(), W[:, :K].double(), 3e-6, 0
+        elif kind == "fp8":
+            Aq, Wq = ops.cast_fp8(Ad, 16.0), ops.cast_fp8(Wd, 2.0 ** 10)
+            alpha = 1.0 / (16.0 * 2.0 ** 10)
+            Ar, Wr, tol = Aq.cpu().float().double() / 16.0, Wq.cpu().float().double() / 2.0 ** 10, 5e-5
+        else:
+            Aq, Wq, alpha, Ar, Wr, tol = Ad, Wd, 1.0, A.double(), W.double(), 3e-6
+        ref = Ar[:, :K] @ Wr[:, :K].T + bias.double()
+        if gelu:
+            ref = torch.nn.functional.gelu(ref)
+        if res is not None:
+            ref = ref + res.double()
+        kw = dict(bias=bias.to(DEV), alpha=alpha, act=ops.ACT_GELU if gelu else ops.ACT_NONE)
+        if kind != "f16s":
+            kw.update(lda=K + pad, ldw=K + pad)
+        if res is not None:
+            kw.update(residual=res.to(DEV))
+        out = ops.gemm(Aq, Wq, M, N, K, **kw)
+        err = _rel(out, ref)
+        assert err < tol, (it, kind, M, N, K, pad, gelu, res is not None, err)
