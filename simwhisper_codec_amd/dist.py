@@ -39,8 +39,11 @@ def partition(weights, world):
 class DataParallelCodec:
     """Wraps a codec object (AudioCodec surface: encode/decode returning the reference's dicts)."""
 
-    def __init__(self, codec, device, group=None):
+    def __init__(self, codec, device, group=None, comm_device=None):
+        """comm_device: where the point-to-point buffers live (default: `device`, i.e. RCCL sends straight from HBM
+        over xGMI; "cpu" for a gloo group driving HIP codecs, as the single-card test does)."""
         self.codec, self.device, self.group = codec, torch.device(device), group
+        self.comm = torch.device(comm_device) if comm_device is not None else self.device
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
@@ -48,28 +51,28 @@ class DataParallelCodec:
     def _fan_out(self, flats, sizes, dtype):
         """rank 0: flats[r] is the 1-D tensor for rank r.  Returns this rank's tensor."""
         if self.rank == 0:
-            ops = [dist.P2POp(dist.isend, flats[r], r, self.group) for r in range(1, self.world) if sizes[r] > 0]
+            ops = [dist.P2POp(dist.isend, flats[r].to(self.comm), r, self.group) for r in range(1, self.world) if sizes[r] > 0]
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
             return flats[0]
-        buf = torch.empty(sizes[self.rank], device=self.device, dtype=dtype)
+        buf = torch.empty(sizes[self.rank], device=self.comm, dtype=dtype)
         if sizes[self.rank] > 0:
             for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, 0, self.group)]):
                 w.wait()
-        return buf
+        return buf.to(self.device)
 
     def _fan_in(self, flat, sizes, dtype):
         """every rank contributes a 1-D tensor; rank 0 returns the list of all of them."""
         if self.rank == 0:
-            bufs = [flat] + [torch.empty(sizes[r], device=self.device, dtype=dtype) for r in range(1, self.world)]
+            bufs = [flat] + [torch.empty(sizes[r], device=self.comm, dtype=dtype) for r in range(1, self.world)]
             ops = [dist.P2POp(dist.irecv, bufs[r], r, self.group) for r in range(1, self.world) if sizes[r] > 0]
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
-            return bufs
+            return [bufs[0]] + [b.to(self.device) for b in bufs[1:]]
         if sizes[self.rank] > 0:
-            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, 0, self.group)]):
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat.to(self.comm), 0, self.group)]):
                 w.wait()
         return None
 
