@@ -265,7 +265,7 @@ void dwconv7_ln_kernel(const float* __restrict__ x, OutT* __restrict__ y,
 
 // ------------------------------------------------------ anti-aliased SnakeBeta
 struct Filt12 { float f[12]; };
-constexpr int SN_TS = 32;  // outputs per thread strip
+constexpr int SN_TS = 8;   // outputs per thread strip (6 halo pairs are recomputed per strip: short strips trade 1.75x the sines for 4x the parallelism on these small tensors)
 
 template <typename OutT>
 __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__ x, OutT* __restrict__ y,
@@ -288,7 +288,9 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
     // xw[k] = x[clamp(u - 3 + k)], k = 0..6 for the current up-sample pair u
     // up[2u]   = 2 * sum_{d=-3..2} x[u+d] f[5-2d];  up[2u+1] = 2 * sum_{d=-2..3} x[u+d] f[6-2d]
     auto act = [&](float v) -> float {
-        const float sn = sinf(v * al);
+        // bf16 outputs (decode side of the bf16-class presets) take the hardware sine (v_sin_f32, |error| ~1e-6 on
+        // these arguments); f32 / split-f16 outputs keep the exact sinf: the down-sampler feeds the FSQ rounding
+        const float sn = __is_same(OutT, bf16_t) ? __sinf(v * al) : sinf(v * al);
         return v + ib * (sn * sn);
     };
     // a-window for output t: a[clamp(2t - 5 + k)], k = 0..11  => pairs u = t-3 .. t+3 (partially)
