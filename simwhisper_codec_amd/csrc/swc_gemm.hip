@@ -596,6 +596,12 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
         }
         if (forced == 8 || forced == 6 || forced == 4) mt = forced;
     }
+    // small grids: when the 128 x 128 tiling leaves CU slots empty (4-wave workgroups, two per CU), 64-row tiles double
+    // the workgroup count (down- / up-sampler k7 convs: 6048 x 512 outputs = 192 tiles on 512 slots)
+    static int small_env = -1;
+    if (small_env < 0) small_env = getenv("SWC_GEMM_SMALL") ? atoi(getenv("SWC_GEMM_SMALL")) : 1;
+    const long tiles128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
+    const bool half_rows = small_env && tiles128 < 384 && a->M >= 512;
     if (f8) {
 #define SWC_LAUNCH8(MT, WM, WN)                                                   \
     (cd == SWC_BF16 ? launch<SWC_FP8, bf16_t, MT, WM, WN>(p, s)                     \
@@ -609,7 +615,7 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
         if (big)
             rc = mt == 8 ? SWC_LAUNCH(SWC_BF16, 8, 2, 4) : (mt == 6 ? SWC_LAUNCH(SWC_BF16, 6, 2, 4) : SWC_LAUNCH(SWC_BF16, 4, 2, 4));
         else
-            rc = SWC_LAUNCH(SWC_BF16, 4, 2, 2);
+            rc = half_rows ? SWC_LAUNCH(SWC_BF16, 2, 2, 2) : SWC_LAUNCH(SWC_BF16, 4, 2, 2);
     } else if (fs) {
         bool bigs = a->N >= 256 && big_tiles >= 96;
         if (tile_override() == 128) bigs = false;
@@ -617,7 +623,7 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
         if (bigs)
             rc = mt == 8 ? SWC_LAUNCH(SWC_F16S, 8, 2, 4) : (mt == 6 ? SWC_LAUNCH(SWC_F16S, 6, 2, 4) : SWC_LAUNCH(SWC_F16S, 4, 2, 4));
         else
-            rc = SWC_LAUNCH(SWC_F16S, 4, 2, 2);
+            rc = half_rows ? SWC_LAUNCH(SWC_F16S, 2, 2, 2) : SWC_LAUNCH(SWC_F16S, 4, 2, 2);
     } else {
         rc = SWC_LAUNCH(SWC_F32, 4, 2, 2);
     }
