@@ -234,6 +234,22 @@ def test_vocos_halo_trim_is_exact(tag, precision):
         assert torch.equal(a, b)
 
 
+def test_large_batch_equals_small_batches():
+    """Rows are independent: a batch of 96 equal-length utterances (long persistent tile walks, several window rows)
+    must give, bit for bit, what batches of 8 give."""
+    from simwhisper_codec_amd import synth
+    m = model("real", "mixed")
+    wavs = [synth.synth_audio(16000 * 2, index=800 + i, kind="speech" if i % 3 else "noise").to(DEV) for i in range(96)]
+    big_c = m.encode(wavs)["codes_list"]
+    big_w = m.decode(big_c)["syn_wav_list"]
+    for i0 in range(0, 96, 8):
+        c = m.encode(wavs[i0:i0 + 8])["codes_list"]
+        w = m.decode(c)["syn_wav_list"]
+        for k in range(8):
+            assert torch.equal(c[k], big_c[i0 + k])
+            assert torch.equal(w[k], big_w[i0 + k])
+
+
 def test_api_edge_cases():
     """inputs on the host, empty members, single utterance, float64 audio: same answers as the oracle."""
     from simwhisper_codec_amd import synth
