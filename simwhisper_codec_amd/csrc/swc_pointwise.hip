@@ -528,24 +528,52 @@ __global__ void deconv_col2im_kernel(const float* __restrict__ y3, const float* 
     store_out<OutT>(out + ((long)b * t_out + to) * ldo + c, v);
 }
 
-// -------------------------------------------------------------------- ISTFT
+// 4 channels per thread (C % 4 == 0, ldo % 4 == 0): float4 taps in, one 8 / 16-byte store out
 template <typename OutT>
-__global__ void istft_spec_kernel(const float* __restrict__ h, long ldh, OutT* __restrict__ s, long lds,
-                                  long rows) {
+__global__ void deconv_col2im4_kernel(const float* __restrict__ y3, const float* __restrict__ bias,
+                                      OutT* __restrict__ out, long ldo, int T, int C, int s, int t_out) {
+    const int b = blockIdx.y;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long half = lds;  // one thread per (row, col) of the output
-    if (i >= rows * half) return;
-    const long r = i / lds;
-    const int c = (int)(i - r * lds);
-    float v = 0.f;
-    if (c < 642) {
-        const int k = c < 321 ? c : c - 321;
-        float mag = expf(h[r * ldh + k]);
-        mag = fminf(mag, 100.0f);
-        const float ph = h[r * ldh + 321 + k];
-        v = c < 321 ? mag * cosf(ph) : mag * sinf(ph);
+    const long q = ldo >> 2;
+    if (i >= (long)t_out * q) return;
+    const int to = (int)(i / q);
+    const int c = (int)(i - (long)to * q) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {
+        v = *reinterpret_cast<const float4*>(bias + c);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int d = to - j;
+            if (d >= 0 && d % s == 0) {
+                const int ti = d / s;
+                if (ti < T) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(y3 + (((long)b * T + ti) * 3 + j) * C + c);
+                    v.x += t4.x; v.y += t4.y; v.z += t4.z; v.w += t4.w;
+                }
+            }
+        }
     }
-    store_out<OutT>(s + r * lds + c, v);
+    store4<OutT>(out + ((long)b * t_out + to) * ldo + c, v.x, v.y, v.z, v.w);
+}
+
+// -------------------------------------------------------------------- ISTFT
+// one thread per (row, bin): magnitude and phase are read once and feed both the real and the imaginary column
+template <typename OutT>
+__global__ void istft_spec2_kernel(const float* __restrict__ h, long ldh, OutT* __restrict__ s, long lds, long rows) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 321 + (int)(lds - 642);  // bins + the zero columns beyond 642
+    if (i >= rows * per) return;
+    const long r = i / per;
+    const int k = (int)(i - r * per);
+    if (k >= 321) {
+        store_out<OutT>(s + r * lds + 642 + (k - 321), 0.f);
+        return;
+    }
+    float mag = expf(h[r * ldh + k]);
+    mag = fminf(mag, 100.0f);
+    const float ph = h[r * ldh + 321 + k];
+    store_out<OutT>(s + r * lds + k, mag * cosf(ph));
+    store_out<OutT>(s + r * lds + 321 + k, mag * sinf(ph));
 }
 
 __global__ void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ wsq,
@@ -799,6 +827,16 @@ extern "C" int swc_deconv_col2im(const float* y3, const float* bias, void* out, 
     SWC_CHECK_ARG(t_out <= (T - 1) * s_ + 3, "swc_deconv_col2im: t_out too large");
     if (B <= 0 || T <= 0 || t_out <= 0) return SWC_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (C % 4 == 0 && ldo % 4 == 0 && aligned16(y3) && aligned16(bias) && aligned16(out)) {
+        dim3 grid4(nblk((long)t_out * (ldo / 4), 256), B);
+        OUT_DISPATCH(out_dtype,
+                     hipLaunchKernelGGL(deconv_col2im4_kernel<float>, grid4, dim3(256), 0, s, y3, bias, (float*)out,
+                                        (long)ldo, T, C, s_, t_out),
+                     hipLaunchKernelGGL(deconv_col2im4_kernel<bf16_t>, grid4, dim3(256), 0, s, y3, bias, (bf16_t*)out,
+                                        (long)ldo, T, C, s_, t_out));
+        SWC_CHECK_LAUNCH("swc_deconv_col2im");
+        return SWC_OK;
+    }
     dim3 grid(nblk((long)t_out * ldo, 256), B);
     OUT_DISPATCH(out_dtype,
                  hipLaunchKernelGGL(deconv_col2im_kernel<float>, grid, dim3(256), 0, s, y3, bias, (float*)out,
@@ -814,11 +852,11 @@ extern "C" int swc_istft_spec(const float* h, int64_t ldh, void* sp, int64_t lds
     SWC_CHECK_ARG(h && sp && ldh >= 642 && lds >= 642, "swc_istft_spec: bad args");
     if (rows <= 0) return SWC_OK;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(nblk(rows * lds, 256));
+    dim3 grid(nblk(rows * (321 + (lds - 642)), 256));
     OUT_DISPATCH(s_dtype,
-                 hipLaunchKernelGGL(istft_spec_kernel<float>, grid, dim3(256), 0, s, h, (long)ldh, (float*)sp,
+                 hipLaunchKernelGGL(istft_spec2_kernel<float>, grid, dim3(256), 0, s, h, (long)ldh, (float*)sp,
                                     (long)lds, (long)rows),
-                 hipLaunchKernelGGL(istft_spec_kernel<bf16_t>, grid, dim3(256), 0, s, h, (long)ldh, (bf16_t*)sp,
+                 hipLaunchKernelGGL(istft_spec2_kernel<bf16_t>, grid, dim3(256), 0, s, h, (long)ldh, (bf16_t*)sp,
                                     (long)lds, (long)rows));
     SWC_CHECK_LAUNCH("swc_istft_spec");
     return SWC_OK;
