@@ -360,14 +360,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     const int fr = lane & 15, fh = lane >> 4;
     const int a_row0 = wr * (MT * 16) + fr;
     const int b_row0 = wc * 64 + 16 * (fr >> 2) + (fr & 3);
-    auto read_frags = [&](int stage, int g, uint4(&fa)[MT], uint4(&fb)[4]) {
-        const char* sa = smem + stage * STAGE_BYTES;
-        const char* sb = sa + A_BYTES;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const uint4*>(sb + lds_off<RB>(b_row0 + 4 * j, fh + 4 * g));
-#pragma unroll
-        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const uint4*>(sa + lds_off<RB>(a_row0 + 16 * i, fh + 4 * g));
-    };
     stage_slice(0, 0);
     dma_fence();
     for (;;) {
