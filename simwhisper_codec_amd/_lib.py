@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  (must precede CDLL: shares PyTorch's HIP runtime)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libswc_hip.so")
+# SWC_LIB: an alternative build of the same ABI (A/B benchmarking of compiler flags / kernel variants)
+LIB_PATH = os.environ.get("SWC_LIB") or os.path.join(HERE, "libswc_hip.so")
 
 F32, BF16, F16S, FP8 = 0, 1, 2, 3
 F16S_ACT_SCALE = 64.0  # SWC_F16S_ACT_SCALE in include/swc.h
