@@ -232,6 +232,14 @@ int swc_cast_f32_f16s(const float* x, int64_t ldx, void* y, int64_t rows, int32_
  * attention outputs) */
 int swc_cast_fp8(const void* x, int32_t x_dtype, void* y, int64_t n, float scale, void* stream);
 
+/*
+ * Batch assembly: n_rows separate device buffers (row i: nbytes[i] bytes at src[i], 4-byte aligned, nbytes % 4 == 0)
+ * -> one [n_rows][ld_bytes] buffer, zero-filled beyond each row's length.  Replaces the per-utterance copy loops of
+ * model.py:258-262,322-326 (the reference pads on the host); `src` and `nbytes` are DEVICE arrays.
+ */
+int swc_gather_rows(const void* const* src, const int64_t* nbytes, void* out, int64_t ld_bytes, int32_t n_rows,
+                    void* stream);
+
 
 #ifdef __cplusplus
 }

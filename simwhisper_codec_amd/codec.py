@@ -440,15 +440,16 @@ class AudioCodec(nn.Module):
     # torch.tensor(list, device=...) copies from pageable memory and synchronises the stream every time
     _PIN_SLOTS, _PIN_LEN = 32, 4096
 
-    def _dev_ints(self, values, dev):
+    def _dev_ints(self, values, dev, dtype=torch.int32, cache_it=True):
         n = len(values)
         dev = torch.device(dev)
-        if n == 0 or n > self._PIN_LEN or dev.type != "cuda":
-            return torch.tensor(values, dtype=torch.int32, device=dev)
+        per = 1 if dtype == torch.int32 else 2  # int64 entries take two int32 slots of the staging row
+        if n == 0 or n * per > self._PIN_LEN or dev.type != "cuda":
+            return torch.tensor(values, dtype=dtype, device=dev)
         # recurring shapes (serving, benchmarks, graph capture) re-use the uploaded tensor: nothing is copied at all
         cache = self.__dict__.setdefault("_ints_cache", {})
-        key = (dev, tuple(values))
-        hit = cache.get(key)
+        key = (dev, dtype, tuple(values)) if cache_it else None
+        hit = cache.get(key) if cache_it else None
         if hit is not None:
             return hit
         if torch.cuda.is_current_stream_capturing():
@@ -464,14 +465,15 @@ class AudioCodec(nn.Module):
         st["i"] = (i + 1) % self._PIN_SLOTS
         if st["ev"][i] is not None:
             st["ev"][i].synchronize()  # the copy that last used this row finished 32 uploads ago
-        row = st["buf"][i, :n]
-        row.copy_(torch.tensor(values, dtype=torch.int32))
-        out = torch.empty(n, dtype=torch.int32, device=dev)
+        row = st["buf"][i, :n * per].view(dtype)
+        row.copy_(torch.tensor(values, dtype=dtype))
+        out = torch.empty(n, dtype=dtype, device=dev)
         out.copy_(row, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
         st["ev"][i] = ev
-        cache[key] = out
+        if cache_it:
+            cache[key] = out
         return out
 
     # ------------------------------------------------- reference entry points
@@ -518,10 +520,16 @@ class AudioCodec(nn.Module):
     max_rows_per_call = 64
     trim_vocos = True  # decode(): run Vocos only on the kept frames (+ halo) of each window; bit-identical output
 
-    @staticmethod
-    def _stack(tensors, lens, dev, dtype):
-        """list of 1-D tensors -> zero-padded [B, max(len)] on dev (one kernel when lengths are equal)."""
+    def _stack(self, tensors, lens, dev, dtype):
+        """list of 1-D tensors -> zero-padded [B, max(len)] on dev.  Device-resident 4-byte rows (the normal case) are
+        assembled by one gather kernel from an uploaded address list instead of one copy per utterance."""
         L = max(max(lens), 1)
+        if (dev.type == "cuda" and dtype in (torch.float32, torch.int32) and len(tensors) <= 65535
+                and all(t.device == dev and t.dtype == dtype and t.is_contiguous() and t.data_ptr() % 4 == 0
+                        for t in tensors)):
+            ptrs = self._dev_ints([t.data_ptr() for t in tensors], dev, torch.int64, cache_it=False)
+            nbytes = self._dev_ints([4 * n for n in lens], dev, torch.int64)
+            return ops.gather_rows(ptrs, nbytes, len(tensors), L, dtype, dev)
         if len(set(lens)) == 1 and lens[0] > 0 and all(t.device == dev and t.dtype == dtype for t in tensors):
             return torch.stack([t.reshape(-1) for t in tensors])
         out = torch.zeros(len(tensors), L, device=dev, dtype=dtype)
@@ -593,7 +601,19 @@ class AudioCodec(nn.Module):
         dev = self._buffers_device() if device is None else torch.device(device)
         if L == 0:
             return {"syn_wav_list": [torch.zeros(0, device=dev) for _ in range(B)]}
-        if len(set(n)) == 1 and n[0] == L and all(c.device == dev and c.dtype == codes_list[0].dtype for c in codes_list):
+        G = self.num_groups
+        dt0 = codes_list[0].dtype
+        if (dev.type == "cuda" and dt0 in (torch.int32, torch.int64) and B * G <= 65535
+                and all(c.device == dev and c.dtype == dt0 and c.dim() == 2 and c.shape[0] == G
+                        and (c.shape[1] == 0 or c.stride(1) == 1) for c in codes_list)):
+            # one gather kernel over the B x G code rows (they may be strided views of encode()'s output)
+            es = 4 if dt0 == torch.int32 else 8
+            ptrs = [c.data_ptr() + g * c.stride(0) * es for c in codes_list for g in range(G)]
+            nb = [es * v for v in n for _ in range(G)]
+            rows = ops.gather_rows(self._dev_ints(ptrs, dev, torch.int64, cache_it=False),
+                                   self._dev_ints(nb, dev, torch.int64), B * G, L, dt0, dev)
+            codes = rows.view(B, G, L).permute(1, 0, 2).to(torch.long)
+        elif len(set(n)) == 1 and n[0] == L and all(c.device == dev and c.dtype == dt0 for c in codes_list):
             codes = torch.stack(list(codes_list), dim=1).to(torch.long)  # one conversion, not one per utterance
         else:
             codes = torch.zeros(self.num_groups, B, L, device=dev, dtype=torch.long)

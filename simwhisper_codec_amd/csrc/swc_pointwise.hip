@@ -893,6 +893,49 @@ extern "C" int swc_cast_f32_bf16(const float* x, void* y, int64_t n, void* strea
     return SWC_OK;
 }
 
+namespace {
+// grid (chunks, rows): dword copy of row r with zero fill up to ld (16-byte vectors when everything is aligned)
+__global__ void gather_rows_kernel(const void* const* __restrict__ src, const int64_t* __restrict__ nbytes,
+                                   unsigned* __restrict__ out, long ld_words) {
+    const int r = blockIdx.y;
+    const unsigned* s = reinterpret_cast<const unsigned*>(src[r]);
+    const long n = nbytes[r] >> 2;
+    unsigned* o = out + (long)r * ld_words;
+    const bool v4 = ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(o)) & 15) == 0 && (ld_words & 3) == 0;
+    const long stride = (long)gridDim.x * blockDim.x;
+    if (v4) {
+        const long n4 = n >> 2, l4 = ld_words >> 2;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < l4; i += stride) {
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (i < n4) {
+                v = reinterpret_cast<const uint4*>(s)[i];
+            } else if (4 * i < n) {  // the row ends inside this vector
+                unsigned t[4] = {0u, 0u, 0u, 0u};
+                for (int k = 0; k < 4 && 4 * i + k < n; ++k) t[k] = s[4 * i + k];
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            reinterpret_cast<uint4*>(o)[i] = v;
+        }
+    } else {
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < ld_words; i += stride) o[i] = i < n ? s[i] : 0u;
+    }
+}
+}  // namespace
+
+extern "C" int swc_gather_rows(const void* const* src, const int64_t* nbytes, void* out, int64_t ld_bytes,
+                               int32_t n_rows, void* stream) {
+    SWC_CHECK_ARG(src && nbytes && out, "swc_gather_rows: null pointer");
+    SWC_CHECK_ARG(ld_bytes >= 0 && ld_bytes % 4 == 0 && n_rows >= 0 && n_rows <= 65535, "swc_gather_rows: bad shape");
+    if (n_rows == 0 || ld_bytes == 0) return SWC_OK;
+    const long words = ld_bytes / 4;
+    long chunks = nblk(nblk(words, 4), 256);
+    if (chunks > 64) chunks = 64;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)chunks, n_rows), dim3(256), 0, (hipStream_t)stream, src,
+                       nbytes, (unsigned*)out, words);
+    SWC_CHECK_LAUNCH("swc_gather_rows");
+    return SWC_OK;
+}
+
 extern "C" int swc_cast_fp8(const void* x, int32_t x_dtype, void* y, int64_t n, float scale, void* stream) {
     SWC_CHECK_ARG(x && y, "swc_cast_fp8: null pointer");
     SWC_CHECK_ARG(x_dtype == SWC_F32 || x_dtype == SWC_BF16, "swc_cast_fp8: bad x_dtype");

@@ -239,3 +239,12 @@ def cast_f16s(x, K, scale=F16S_ACT_SCALE, ldx=None):
     y = torch.empty((rows, 2 * K), device=x.device, dtype=torch.float16)
     _lib.check(lib.swc_cast_f32_f16s(_ptr(x), ldx, _ptr(y), rows, K, scale, _stream()), "swc_cast_f32_f16s")
     return y
+
+
+def gather_rows(ptrs_dev, nbytes_dev, n_rows, ld_elems, dtype, device):
+    """n_rows device buffers (int64 device arrays of addresses / byte counts) -> zero-padded [n_rows, ld_elems]."""
+    lib = _lib.load()
+    out = torch.empty((n_rows, ld_elems), device=device, dtype=dtype)
+    _lib.check(lib.swc_gather_rows(_ptr(ptrs_dev), _ptr(nbytes_dev), _ptr(out), ld_elems * out.element_size(), n_rows,
+                                   _stream()), "swc_gather_rows")
+    return out

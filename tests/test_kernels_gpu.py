@@ -629,3 +629,24 @@ def test_gemm_shape_fuzz():
         out = ops.gemm(Aq, Wq, M, N, K, **kw)
         err = _rel(out, ref)
         assert err < tol, (it, kind, M, N, K, pad, gelu, res is not None, err)
+
+
+def test_gather_rows():
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    lens = [0, 1, 5, 1000, 777, 4096, 3]
+    for dtype in (torch.float32, torch.int32, torch.int64):
+        rows = [(torch.randn(n, generator=g) * 100).to(dtype).to(DEV) for n in lens]
+        # an unaligned (4-byte but not 16-byte) source and a strided parent
+        parent = (torch.randn(3, 2000, generator=g) * 100).to(dtype).to(DEV)
+        rows += [parent[1, 1:1 + 501], parent[2, :64]]
+        ln = lens + [501, 64]
+        es = rows[0].element_size()
+        L = max(ln) + 5
+        ptrs = torch.tensor([r.data_ptr() for r in rows], dtype=torch.int64, device=DEV)
+        nb = torch.tensor([es * n for n in ln], dtype=torch.int64, device=DEV)
+        out = ops.gather_rows(ptrs, nb, len(rows), L, dtype, torch.device(DEV))
+        want = torch.zeros(len(rows), L, dtype=dtype)
+        for i, r in enumerate(rows):
+            want[i, : ln[i]] = r.cpu()
+        assert torch.equal(out.cpu(), want)
