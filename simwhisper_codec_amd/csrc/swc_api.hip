@@ -11,7 +11,7 @@ void swc_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int swc_version(void) { return 101; }
+extern "C" int swc_version(void) { return 110; }  // 1.10: + fp8 mode, swc_cast_fp8, swc_gather_rows
 
 extern "C" const char* swc_last_error(void) { return g_err; }
 
