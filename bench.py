@@ -4,21 +4,31 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = one pass of the hot path (AudioCodec.encode then AudioCodec.decode) over one batch of
-synthetic 16 kHz audio already resident in HBM: 32 utterances x 10 s per GPU (BASELINE.json's
-metric shape; weak scaling: every rank processes its own 32 utterances, no data-path collective).
-Weights: the closed-form synthetic checkpoint (291 M parameters, random-init statistics).
+A step = one pass of the hot path over one batch of synthetic 16 kHz audio already resident in HBM: 32 utterances x
+10 s per GPU (BASELINE.json's metric shape; SURVEY.md 8d inputs: 0.1 * N(0,1), torch.Generator seed 1234, one draw per
+utterance in order).  Weights: the closed-form synthetic checkpoint (291 M parameters, random-init statistics).
+
+Two measurements, each W warm-up steps then EXACTLY K timed steps bracketed by barrier + device sync, MAX over ranks:
+  scatter_gather  (`value`)  — BASELINE.json configs[3]: rank 0 owns all N x 32 utterances in its HBM; a step is
+        DataParallelCodec.encode_decode on the RCCL backend: scatter of the audio over xGMI, encode -> decode on every
+        GPU, gather of codes and waveforms back to rank 0, all inside the timed region.  For N = 1 the scatter / gather
+        degenerates to the single-GPU step (a single-rank RCCL group is still initialised, so the code path is the same).
+  independent_shards (second field) — every rank encodes + decodes its own 32 utterances; no data-path traffic at all.
 Rank 0 prints ONE JSON line, with
-  roofline     — the dominant kernel family (swc_gemm, by accumulated device time), timed live with
-                 events on the launching stream inside the timed steps (every 5th timed step, counting back
-                 from the last, carries the event pairs); achieved = 2*M*N*K*taps summed over the sampled
-                 launches / their summed duration; peak = dense MFMA peak of its dtype.
-  cpu_baseline — the CPU oracle (oracle/ref_cpu.py, the reference's algorithm incl. its 30 s padding)
-                 timed on this box's host cores on a bounded sample of the same workload (N=1 only).
+  roofline     — the dominant kernel family (by accumulated device time), timed live with events on the launching stream
+                 inside the timed steps (every 5th timed step, counting back from the last, carries the event pairs);
+                 achieved = algorithmic FLOPs of the sampled launches / their summed duration; peak = dense MFMA peak of
+                 its dtype; traffic = HBM bytes per launch from the committed rocprofv3 --pmc passes, tagged with the commit
+                 they were taken at (a stale value is visible as a different commit).
+  cpu_baseline — the CPU oracle (oracle/ref_cpu.py, the reference's algorithm incl. its 30 s padding) timed on this
+                 box's host cores on a bounded sample of the same workload (N = 1 only): 1 warm-up + 3 timed passes, median.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -28,13 +38,15 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import yaml  # noqa: E402
 
-# MI355X dense MFMA peaks (MI355X_MICROARCH.md).  gemm_f16s executes 3 f16 MFMA passes per algorithmic
-# multiply-add (hi*hi + hi*lo + lo*hi), so its ceiling in algorithmic FLOP/s is 2500 / 3.
-PEAK_TFLOPS = {"gemm_bf16": 2500.0, "gemm_f32": 157.3, "gemm_f16s": 2500.0 / 3.0, "gemm_fp8": 5000.0}
+# MI355X dense MFMA peaks (MI355X_MICROARCH.md).  gemm_f16s executes 3 f16 MFMA passes per algorithmic multiply-add
+# (hi*hi + hi*lo + lo*hi), so its ceiling in algorithmic FLOP/s is 2500 / 3.  gemm_fp8 runs on the block-scaled
+# v_mfma_scale_f32_16x16x128_f8f6f4 (2x the bf16 rate).
+PEAK_TFLOPS = {"gemm_bf16": 2500.0, "convnext_bf16": 2500.0, "gemm_f32": 157.3, "gemm_f16s": 2500.0 / 3.0,
+               "gemm_fp8": 5000.0}
 
 
-class GemmTimer:
-    """Per-launch event pairs around swc_gemm (ops.PROFILER hook)."""
+class KernelTimer:
+    """Per-launch event pairs around the MFMA kernels (ops.PROFILER hook), on the launching stream."""
 
     def __init__(self):
         self.rec = []
@@ -62,29 +74,66 @@ class GemmTimer:
 
 
 def pmc_traffic(kind):
-    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 --pmc passes
-    (profiles/r01_pmc_gemm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes of this
-    same command).  PMC cannot be collected from inside the timed run, so this is the profiled value, or None."""
+    """(HBM bytes per launch, provenance) of a kernel family from the committed rocprofv3 --pmc passes of this same command
+    (tools/pmc_traffic.sh: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes).  PMC counters cannot be
+    collected from inside the timed run, so this is the profiled value with the commit it was taken at, or (None, None)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_gemm_traffic.json")) as f:
-            return round(json.load(f)[kind]["hbm_bytes_per_launch"])
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as f:
+            d = json.load(f)
+        return round(d[kind]["hbm_bytes_per_launch"]), {"profile": d.get("_profile"), "commit": d.get("_commit")}
     except Exception:
-        return None
+        return None, None
 
 
-def cpu_baseline(gp, sd, n_utt, seconds, threads):
+def bench_inputs(n_utt, n_samples):
+    """SURVEY.md 8d / BASELINE.md 2: 0.1 * N(0,1), torch.Generator().manual_seed(1234), one draw per utterance in order."""
+    g = torch.Generator().manual_seed(1234)
+    return [0.1 * torch.randn(n_samples, generator=g) for _ in range(n_utt)]
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(gp, sd, shapes, seconds, threads):
+    """oracle/ref_cpu.py on the host cores: per shape 1 warm-up + 3 timed encode+decode passes, median."""
     from oracle.ref_cpu import Oracle
-    from simwhisper_codec_amd import synth
     torch.set_num_threads(threads)
     ora = Oracle(gp, sd)
-    wavs = [synth.synth_audio(int(seconds * 16000), index=1000 + i) for i in range(n_utt)]
-    t0 = time.perf_counter()
-    codes = ora.encode(wavs)["codes_list"]
-    ora.decode(codes)
-    dt = time.perf_counter() - t0
-    return {"value": round(n_utt * seconds / dt, 3), "unit": "audio-s/s", "cores": threads, "kind": "port",
-            "sample": f"{n_utt} x {seconds:g} s utterances, encode+decode once, fp32, oracle/ref_cpu.py "
-                      f"(reference algorithm incl. 30 s padding), {dt:.1f} s wall"}
+    res = []
+    t_all = time.perf_counter()
+    for n_utt in shapes:
+        wavs = bench_inputs(n_utt, int(seconds * 16000))
+        times = []
+        for it in range(4):
+            t0 = time.perf_counter()
+            codes = ora.encode(wavs)["codes_list"]
+            ora.decode(codes)
+            if it:
+                times.append(time.perf_counter() - t0)
+        res.append({"batch": n_utt, "audio-s/s": round(n_utt * seconds / statistics.median(times), 3),
+                    "pass_s": [round(t, 2) for t in times]})
+    head = res[-1]
+    return {"value": head["audio-s/s"], "unit": "audio-s/s", "cores": threads, "kind": "port", "cpu": cpu_model(),
+            "sample": f"{head['batch']} x {seconds:g} s utterances (same generator as the GPU run), 1 warm-up + 3 timed "
+                      f"encode+decode passes, median; fp32, oracle/ref_cpu.py (reference algorithm incl. 30 s padding); "
+                      f"{time.perf_counter() - t_all:.0f} s of CPU work",
+            "shapes": res}
+
+
+def git_commit():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, text=True, timeout=5).stdout.strip() or None
+    except Exception:
+        return None
 
 
 def main():
@@ -95,28 +144,41 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--precision", default="mixed", choices=["fp32", "mixed", "mixed_f32", "bf16", "fp8"])
-    ap.add_argument("--cpu-utts", type=int, default=8, help="utterances in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--no-gemm-timer", action="store_true")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "off"],
+                    help="sample: 2 utterances (~15 s of CPU work); full: B=8 and B=32 as BASELINE.md 2 (minutes)")
+    ap.add_argument("--no-timer", action="store_true", help="no per-launch event pairs (no roofline object)")
+    ap.add_argument("--no-dist", action="store_true", help="N=1 only: skip the process group and the scatter/gather measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    # one process per GPU over RCCL; also initialised for a single rank launched by torch.distributed.run, so that the
-    # N > 1 code path (init, barrier, MAX all-reduce) can be exercised on a one-GPU box
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    if use_dist:
+    # one process per GPU over RCCL.  A single rank also gets its (one-member) group, so that N = 1 runs the very code
+    # path the 8-GPU node runs: init, tensor broadcasts, barrier, MAX all-reduce, DataParallelCodec.
+    use_dist, dist_note = False, None
+    if world > 1 or not args.no_dist:
         import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
+            import datetime
+            # a failed peer must not leave the others waiting for the default 10 minutes
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=240))
+            use_dist = True
+        except Exception as e:  # a single GPU still has its number; N > 1 cannot run without the group
+            if world > 1:
+                raise
+            dist_note = f"single-rank RCCL group unavailable ({type(e).__name__}: {e}); plain single-GPU step timed"
 
     from simwhisper_codec_amd import ops, synth
     from simwhisper_codec_amd.codec import AudioCodec
+    from simwhisper_codec_amd.dist import DataParallelCodec
 
     gp = yaml.safe_load(open(os.path.join(ROOT, "config", "SimWhisperCodec.yaml")))["generator_params"]
     sd = synth.synth_state_dict(gp)
@@ -124,11 +186,9 @@ def main():
     model.load_state_dict(sd, strict=True)
     model = model.to(dev).eval()
     n = int(args.seconds * 16000)
-    wavs = [synth.synth_audio(n, index=rank * args.batch + i).to(dev) for i in range(args.batch)]
-
-    def step():
-        enc = model.encode(wavs, overlap_seconds=10, device=dev)
-        return model.decode(enc["codes_list"], overlap_seconds=10, device=dev)
+    all_wavs = bench_inputs(world * args.batch, n)  # the same draws on every rank; a rank keeps what it needs
+    mine = [w.to(dev) for w in all_wavs[rank * args.batch:(rank + 1) * args.batch]]
+    n_out = (n // 1280) * 1280
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -136,63 +196,125 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    timer = None if args.no_gemm_timer else GemmTimer()
-    # the event pairs cost ~3 % of a step (218 event records), so they are placed on every 5th timed step only
-    sampled = set(range(args.steps - 1, -1, -5))
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ops.PROFILER = timer if i in sampled else None
-        out = step()
-    ops.PROFILER = None
-    fence()
-    elapsed = time.perf_counter() - t0
-    assert len(out["syn_wav_list"]) == args.batch and out["syn_wav_list"][0].shape[0] == (n // 1280) * 1280
+    def timed(step, check, timer):
+        """W warm-ups, then exactly K steps between two fences; returns (seconds MAX over ranks, per-step ms list)."""
+        for _ in range(args.warmup):
+            step()
+        sampled = set(range(args.steps - 1, -1, -5)) if timer is not None else set()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        fence()
+        t0 = time.perf_counter()
+        marks[0].record()
+        out = None
+        for i in range(args.steps):
+            ops.PROFILER = timer if i in sampled else None
+            out = step()
+            marks[i + 1].record()
+        ops.PROFILER = None
+        fence()
+        elapsed = time.perf_counter() - t0
+        check(out)
+        if use_dist:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+        return elapsed, per_step, len(sampled)
+
+    # ---- measurement A: independent shards (no data-path traffic)
+    def step_local():
+        enc = model.encode(mine, overlap_seconds=10, device=dev)
+        return model.decode(enc["codes_list"], overlap_seconds=10, device=dev)
+
+    def check_local(out):
+        assert len(out["syn_wav_list"]) == args.batch and out["syn_wav_list"][0].shape[0] == n_out
+
+    timer = None if args.no_timer else KernelTimer()
+    el_a, steps_a, n_sampled = timed(step_local, check_local, None if use_dist else timer)
+    res_a = {"value": round(world * args.batch * args.seconds * args.steps / el_a, 2),
+             "ms_per_step": round(1e3 * el_a / args.steps, 3), "ms_per_step_median": round(statistics.median(steps_a), 3)}
+
+    # ---- measurement B: rank 0 scatters / gathers over RCCL (configs[3])
+    res_b, b_err = None, None
     if use_dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        try:
+            dp = DataParallelCodec(model, dev)
+            owned = [w.to(dev) for w in all_wavs] if rank == 0 else None
+
+            def step_dp():
+                return dp.encode_decode(owned, overlap_seconds=10)
+
+            def check_dp(out):
+                if rank == 0:
+                    assert len(out["syn_wav_list"]) == world * args.batch and out["syn_wav_list"][-1].shape[0] == n_out
+                    assert len(out["codes_list"]) == world * args.batch and out["codes_list"][-1].shape[-1] == n // 1280
+
+            el_b, steps_b, n_sampled = timed(step_dp, check_dp, timer)
+            res_b = {"value": round(world * args.batch * args.seconds * args.steps / el_b, 2),
+                     "ms_per_step": round(1e3 * el_b / args.steps, 3),
+                     "ms_per_step_median": round(statistics.median(steps_b), 3)}
+        except Exception as e:
+            if world > 1:
+                # every rank fails or none: the error is raised collectively by RCCL; report the shard number with the reason
+                b_err = f"{type(e).__name__}: {e}"
+            else:
+                raise
+    main_res = res_b if res_b is not None else res_a
+    el_main = el_b if res_b is not None else el_a
 
     if rank == 0:
-        audio_s = world * args.batch * args.seconds * args.steps
+        par = (f"dp{world}: rank 0 scatters the audio / gathers codes + waveforms over RCCL point-to-point (xGMI), "
+               f"utterance shards of {args.batch} per GPU" if res_b is not None
+               else f"dp{world} (independent utterance shards, no collective)")
         line = {
             "metric": f"audio-sec/sec encode+decode (RTF^-1), 16kHz batch={args.batch}x{args.seconds:g}s",
-            "value": round(audio_s / elapsed, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "value": main_res["value"], "unit": "audio-s/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
+            "ms_per_step_median": main_res["ms_per_step_median"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "mixed": "split-f16 x3 encode (f32-class, f32 accumulate) / bf16 decode (f32 accumulate)",
                       "mixed_f32": "f32 encode / bf16 decode (f32 accumulate)", "bf16": "bf16",
-                      "fp8": "fp8 (e4m3) encoder-transformer linears / bf16 elsewhere (f32 accumulate)"}[args.precision],
+                      "fp8": "fp8 (e4m3, block-scaled MFMA) encoder-transformer linears / bf16 elsewhere (f32 accumulate)"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"batch={args.batch}x{args.seconds:g}s @16kHz per GPU, encode()+decode(), "
-                                   f"synthetic closed-form checkpoint (291M params)",
-                       "precision": args.precision, "parallelism": f"dp{world} (utterance shards, no collective)"},
+            "config": {"workload": f"batch={args.batch}x{args.seconds:g}s @16kHz per GPU ({world * args.batch} utterances in all), "
+                                   f"encode()+decode(), 0.1*N(0,1) seed 1234, synthetic closed-form checkpoint (291M params)",
+                       "precision": args.precision, "parallelism": par},
+            "independent_shards": res_a,
         }
+        if b_err:
+            line["scatter_gather_error"] = b_err
+        if dist_note:
+            line["note"] = dist_note
         if timer is not None:
             summ = timer.summary()
             if summ:
+                step_ms = 1e3 * el_main / args.steps
                 kind = max(summ, key=lambda k: summ[k]["ms"])
                 d = summ[kind]
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                traffic, src = pmc_traffic(kind)
+                tot_ms = sum(v["ms"] for v in summ.values())
+                tot_fl = sum(v["flops"] for v in summ.values())
                 line["roofline"] = {
-                    "bound": "mfma", "kernel": f"swc_gemm ({kind})", "achieved": round(ach, 2),
-                    "peak": round(PEAK_TFLOPS[kind], 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[kind], 4),
-                    "traffic": pmc_traffic(kind),
-                    # informational: the MFMA-only loop of this kernel (no LDS reads, DMA or barriers) sustains 1500 TFLOP/s
-                    # on random 16-bit data at the clock the chip holds; not used for `frac`
-                    "sustained_mfma_ceiling": {"gemm_bf16": 1500.0, "gemm_f16s": 500.0, "gemm_fp8": 1500.0}.get(kind),
-                    "launches_per_step": d["launches"] // len(sampled), "sampled_steps": len(sampled),
+                    "bound": "mfma", "kernel": {"convnext_bf16": "swc_convnext_mlp (bf16)"}.get(kind, f"swc_gemm ({kind})"),
+                    "achieved": round(ach, 2), "peak": round(PEAK_TFLOPS[kind], 1), "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_TFLOPS[kind], 4), "traffic": traffic, "traffic_source": src,
+                    "launches_per_step": d["launches"] // n_sampled, "sampled_steps": n_sampled,
                     "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                    "share_of_step": round(d["ms"] / len(sampled) / (1e3 * elapsed / args.steps), 3),
+                    "share_of_step": round(d["ms"] / n_sampled / step_ms, 3),
                     "other": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                  "share_of_step": round(v["ms"] / len(sampled) / (1e3 * elapsed / args.steps), 3)}
+                                  "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS[k], 4),
+                                  "launches_per_step": v["launches"] // n_sampled,
+                                  "share_of_step": round(v["ms"] / n_sampled / step_ms, 3)}
                               for k, v in summ.items() if k != kind},
+                    "all_mfma_kernels": {"TFLOP/s": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                         "share_of_step": round(tot_ms / n_sampled / step_ms, 3)},
+                    "commit": git_commit(),
                 }
-        if world == 1 and args.cpu_utts > 0:
-            threads = min(16, os.cpu_count() or 1)
-            line["cpu_baseline"] = cpu_baseline(gp, sd, args.cpu_utts, args.seconds, threads)
+        if world == 1 and args.cpu_baseline != "off":
+            threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+            shapes = [2] if args.cpu_baseline == "sample" else [8, 32]
+            line["cpu_baseline"] = cpu_baseline(gp, sd, shapes, args.seconds, threads)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

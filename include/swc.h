@@ -16,7 +16,7 @@
  *    a negative SWC_E_* code otherwise (swc_last_error() gives the text).
  *    Nothing allocates, synchronises or throws; the caller owns all memory.
  *  - `stream` is a hipStream_t passed as void*.
- *  - dtype codes: SWC_F32 = 0, SWC_BF16 = 1.
+ *  - dtype codes: SWC_F32 = 0, SWC_BF16 = 1, SWC_F16S = 2 (split f16), SWC_FP8 = 3 (OCP e4m3fn); defined below.
  */
 #ifndef SWC_H_
 #define SWC_H_
@@ -64,6 +64,18 @@ int swc_version(void);
 const char* swc_last_error(void);
 /* number of visible HIP devices, or SWC_E_NODEV */
 int swc_device_count(void);
+
+/*
+ * Range guard of the reduced-range operand formats.  The reference computes in fp32 and has no such limit
+ * (modules.py:214-232 only clamps fp16 / bf16 infinities); here split-f16 activations clip at |x| = 65504 / 64 = 1023
+ * and fp8 activations at |x| = 448 / 16 = 28.  `counters` is a caller-owned DEVICE array of two uint32:
+ * [0] += 1 for every thread of a producer kernel (swc_layernorm, swc_snake_aa, swc_gemm epilogue, swc_cast_*) that
+ * clipped at least one split-f16 element, [1] likewise for fp8.  The pointer is kept PER CALLING THREAD (the only
+ * state the library holds besides the error text) and applies to every later call of that thread until replaced;
+ * NULL (the default) turns the accounting off.  The caller zeroes and reads the array; a non-zero count after
+ * an encode means the codes may differ from the reference's and the stage must be re-run on exact-f32 operands.
+ */
+int swc_set_saturation_counter(uint32_t* counters);
 
 /*
  * GEMM / implicit-GEMM Conv1d on MFMA:  C = epi(A (*) W^T)
@@ -129,8 +141,9 @@ int swc_attention_ex(const void* qkv, void* out, const int32_t* lens, int32_t B,
 /*
  * LayerNorm over the last dim.  Replaces nn.LayerNorm calls modules.py:216,224,
  * 353,457 (eps 1e-5) and :1239,1499,1503 (eps 1e-6).  x: [B][t_in][C] f32;
- * y: [B][t_out][C] (y_dtype: F32 | BF16 | F16S at SWC_F16S_ACT_SCALE | FP8 at SWC_FP8_ACT_SCALE).  Only rows t < min(t_in, t_out) are written; when lens != NULL
- * rows t >= lens[b] are written as zeros (torch.where(mask, h, 0), modules.py:358,460).
+ * y: [B][t_out][C] (y_dtype: F32 | BF16 | F16S at SWC_F16S_ACT_SCALE | FP8 at SWC_FP8_ACT_SCALE).  Every output row is written:
+ * rows t >= t_in (t_out > t_in: the zero extension the down-sampler reads) are zeros, and when lens != NULL rows
+ * t >= lens[b] are zeros as well (torch.where(mask, h, 0), modules.py:358,460).
  */
 int swc_layernorm(const float* x, void* y, const float* w, const float* b, const int32_t* lens,
                   int32_t B, int32_t t_in, int32_t t_out, int32_t C, float eps, int32_t y_dtype,

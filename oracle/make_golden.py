@@ -30,7 +30,11 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 
 def import_reference(ref_root):
-    sys.path.insert(0, ref_root)
+    """Import `audiocodec.model.AudioCodec` FROM THE REFERENCE CHECKOUT.  The repo root holds its own regular package
+    `audiocodec/` (the drop-in import path of the product); the reference's `audiocodec/` is a namespace package and
+    would lose to it whatever the order of sys.path.  So: forget any `audiocodec*` module already imported, take the
+    repo root (and the cwd entry) off sys.path for the duration of the import, and check where the module came from."""
+    ref_root = os.path.realpath(ref_root)
     import transformers  # noqa: F401
     import transformers.activations  # noqa: F401
     import transformers.audio_utils  # noqa: F401
@@ -39,8 +43,19 @@ def import_reference(ref_root):
         sys.modules[name] = types.ModuleType(name)
     sys.modules["torchaudio.functional.functional"]._hz_to_mel = None
     sys.modules["torchaudio.functional.functional"]._mel_to_hz = None
-    from audiocodec.model import AudioCodec
-    return AudioCodec
+    for name in [m for m in sys.modules if m == "audiocodec" or m.startswith("audiocodec.")]:
+        del sys.modules[name]
+    saved = list(sys.path)
+    here = {os.path.realpath(ROOT), os.path.realpath(os.getcwd())}
+    sys.path[:] = [ref_root] + [p for p in saved if os.path.realpath(p or os.getcwd()) not in here]
+    try:
+        import audiocodec.model as ref_model
+    finally:
+        sys.path[:] = saved
+    origin = os.path.realpath(ref_model.__file__)
+    if not origin.startswith(ref_root + os.sep):
+        raise RuntimeError(f"audiocodec.model was imported from {origin}, not from the reference at {ref_root}")
+    return ref_model.AudioCodec
 
 
 def tiny_params():
@@ -127,9 +142,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
     ap.add_argument("--only", default=None)
-    ap.add_argument("--cases", default=None, help="'facts' to rewrite only *_facts.npz")
+    ap.add_argument("--cases", default=None, help="'facts' to rewrite only *_facts.npz; a comma list of case names (single,ragged,zeros,short,chunked,forward) to write only those")
+    ap.add_argument("--out", default=None, help="output directory (default tests/golden)")
     args = ap.parse_args()
+    global GOLD
+    if args.out:
+        GOLD = os.path.abspath(args.out)
     os.makedirs(GOLD, exist_ok=True)
+    want = None if args.cases in (None, "facts") else set(args.cases.split(","))
     AudioCodec = import_reference(args.ref)
     torch.manual_seed(0)
     for tag, gp in (("tiny", tiny_params()), ("real", real_params())):
@@ -141,7 +161,7 @@ def main():
         missing = set(model.state_dict()) ^ set(sd)
         assert not missing, f"key mismatch: {sorted(missing)[:8]}"
         model.load_state_dict(sd, strict=True)
-        if args.cases in (None, "facts"):
+        if args.cases in (None, "facts") and want is None:
             # analytic facts about the reference that the tests restate.  The old-style weight-norm hook
             # refreshes `.weight` only inside forward, so run the module once before reading it.
             with torch.inference_mode():
@@ -153,12 +173,15 @@ def main():
                      wn_folded=f32(model.downsample.to_latent.weight))
         if args.cases == "facts":
             continue
-        run_case(model, "single", [("speech", 0, 50000)], tag, stages=True)
-        run_case(model, "ragged", [("noise", 1, 48000), ("speech", 2, 32777)], tag, stages=True)
-        run_case(model, "zeros", [("noise", 3, 20000), ("zero", 0, 16000)], tag)
-        run_case(model, "short", [("speech", 4, 1279), ("noise", 5, 1280), ("noise", 6, 2000)], tag)
-        run_case(model, "chunked", [("speech", 7, 352000), ("noise", 8, 48000)], tag)
-        run_forward_case(model, tag)
+        cases = [("single", [("speech", 0, 50000)], True), ("ragged", [("noise", 1, 48000), ("speech", 2, 32777)], True),
+                 ("zeros", [("noise", 3, 20000), ("zero", 0, 16000)], False),
+                 ("short", [("speech", 4, 1279), ("noise", 5, 1280), ("noise", 6, 2000)], False),
+                 ("chunked", [("speech", 7, 352000), ("noise", 8, 48000)], False)]
+        for name, spec, stages in cases:
+            if want is None or name in want:
+                run_case(model, name, spec, tag, stages=stages)
+        if want is None or "forward" in want:
+            run_forward_case(model, tag)
 
 
 if __name__ == "__main__":

@@ -63,6 +63,7 @@ SIGNATURES = {
     "swc_cast_f32_f16s": [_P, _L, _P, _L, _I, _F, _P],
     "swc_cast_fp8": [_P, _I, _P, _L, _F, _P],
     "swc_gather_rows": [_P, _P, _P, _L, _I, _P],
+    "swc_set_saturation_counter": [_P],
 }
 PLAIN = {"swc_version": ([], C.c_int), "swc_last_error": ([], C.c_char_p), "swc_device_count": ([], C.c_int)}
 

@@ -18,6 +18,7 @@ Work the reference does and this path provably does not need:
 Ragged `decode` batches are padded to the batch maximum exactly like the reference,
 because its un-masked up-sampler / Vocos make short utterances depend on that maximum.
 """
+import functools
 import logging
 import math
 import os
@@ -26,7 +27,7 @@ import torch
 import torch.nn as nn
 import yaml
 
-from . import ops, spec
+from . import ops, spec, trace
 from ._lib import SwcError
 
 # precision presets: (encode-side GEMM operands, decode-side GEMM operands)
@@ -38,6 +39,24 @@ from ._lib import SwcError
 PRECISIONS = {"fp32": ("f32", "f32"), "mixed": ("f16s", "bf16"), "mixed_f32": ("f32", "bf16"), "bf16": ("bf16", "bf16"),
               "fp8": ("bf16", "bf16")}
 _TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16s": torch.float16}
+
+
+def _on_model_device(fn):
+    """Run a public entry point with the model's GPU as the current device.  Kernels are launched on the current
+    device's stream (ops._stream), so a model on cuda:1 called while cuda:0 is current would otherwise enqueue on the
+    wrong GPU; the reference dispatches by tensor device and has no such requirement."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        dev = self._buffers_device()
+        if dev.type != "cuda":  # empty inputs still return empty results (model.py:303-304); anything else raises in _packed()
+            return fn(self, *a, **k)
+        with torch.cuda.device(dev):
+            ops.set_saturation_counter(self._sat_state(dev)["buf"])
+            try:
+                return fn(self, *a, **k)
+            finally:
+                ops.set_saturation_counter(None)
+    return wrapped
 
 
 class _Node(nn.Module):
@@ -159,6 +178,73 @@ class AudioCodec(nn.Module):
 
     def _buffers_device(self):
         return next(self.buffers()).device
+
+    def _resolve_device(self, device):
+        """`device` argument of encode / decode (model.py:245,311 default torch.device("cuda")): an un-indexed "cuda" means
+        the GPU the weights live on; an explicit other GPU (or the CPU) is an error — the weights do not move per call."""
+        mdev = self._buffers_device()
+        if device is None:
+            return mdev
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is None:
+            return mdev if mdev.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+        if dev != mdev:
+            raise SwcError(f"device={dev} but the model is on {mdev}: move the model with .to() first")
+        return dev
+
+    # ------------------------------------------------- range guard (split-f16 / fp8 operands)
+    # "fallback": an encode whose split-f16 operands clipped (|activation| >= 1023: possible with trained Whisper-style
+    #             outlier channels, never seen with the synthetic checkpoint) is re-run on exact-f32 operands and the
+    #             model stays on `mixed_f32` from then on — the codes equal the reference's either way;
+    # "raise":    SwcError instead; "ignore": count only (saturation_count()).
+    saturation_policy = "fallback"
+
+    def _sat_state(self, dev):
+        st = self.__dict__.get("_sat")
+        if st is None or st["dev"] != dev:
+            st = {"dev": dev, "buf": torch.zeros(2, dtype=torch.int32, device=dev),
+                  "host": torch.zeros(2, dtype=torch.int32).pin_memory(), "seen": [0, 0], "warned": False}
+            self.__dict__["_sat"] = st
+        return st
+
+    def saturation_count(self):
+        """{"f16s": n, "fp8": n}: producer threads that clipped a split-f16 / fp8 activation since the model was moved
+        to its device (include/swc.h swc_set_saturation_counter).  Synchronises the stream."""
+        st = self.__dict__.get("_sat")
+        if st is None:
+            return {"f16s": 0, "fp8": 0}
+        with torch.cuda.device(st["dev"]):
+            st["host"].copy_(st["buf"], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+        n = st["host"].tolist()
+        return {"f16s": int(n[0]), "fp8": int(n[1])}
+
+    def _guarded_encode(self, run):
+        """run(P) enqueues the encode-side kernels of one call and returns its outputs.  After it, the clip counters are
+        read back (one 8-byte copy + stream sync per call; presets without reduced-range encode operands skip it)."""
+        P = self._packed()  # raises for a model that is not on the HIP device
+        e = PRECISIONS[self._precision][0]
+        if e != "f16s" and self._precision != "fp8":
+            return run(P)
+        st = self._sat_state(self._buffers_device())
+        out = run(P)
+        n = self.saturation_count()
+        new16, new8 = n["f16s"] - st["seen"][0], n["fp8"] - st["seen"][1]
+        st["seen"] = [n["f16s"], n["fp8"]]
+        if new8 and not st["warned"]:
+            st["warned"] = True
+            logging.warning("fp8 preset: %d producer threads clipped activations at |x| = 28 in this call "
+                            "(part of this preset's stated tolerance)", new8)
+        if new16 and e == "f16s":
+            if self.saturation_policy == "raise":
+                raise SwcError(f"split-f16 operands clipped ({new16} producer threads saw |activation| >= 1023): the codes of "
+                               "this call are not reliable; use precision='mixed_f32'")
+            if self.saturation_policy == "fallback":
+                logging.warning("split-f16 operands clipped (%d producer threads saw |activation| >= 1023): re-running this "
+                                "call on exact-f32 encoder operands; the model stays on precision='mixed_f32'", new16)
+                self.precision = "mixed_f32" if self._precision == "mixed" else "fp32"
+                out = run(self._packed())
+        return out
 
     # ------------------------------------------------------------- packing
     def _dtypes(self):
@@ -354,6 +440,10 @@ class AudioCodec(nn.Module):
         return h
 
     def _logmel(self, wav, n_dev, n_host, P):
+        with trace.stage("mel"):
+            return self._logmel_impl(wav, n_dev, n_host, P)
+
+    def _logmel_impl(self, wav, n_dev, n_host, P):
         """Whisper log-mel of the valid frames (+2 halo) on the zero-extended, reflect-padded signal
         (feature_extractor.py:86-112). wav: [B, >=max n] f32. Returns mel [B, Tm, 80] (conv1 operand dtype), Tm."""
         B = wav.shape[0]
@@ -368,10 +458,15 @@ class AudioCodec(nn.Module):
         mel = ops.mel_final(mp, P.n_mel, umax, B=B, T=Tm, n_mel=P.n_mel, ldo=P.n_mel, out_dtype=P.c1dt)
         return mel, Tm
 
-    def _encode_mel(self, mel, Tm, t_full, tok_host, P):
-        """conv stem + encoder + down-sampler on frame-major mel [B, Tm, n_mel].
-        t_full: the number of encoder tokens the reference would run (1500 for a 30 s padded call).
-        Returns z [B, Tds, lat] f32, Tds, latent lengths (host list)."""
+    def _encoder(self, mel, Tm, t_full, tok_host, P):
+        with trace.stage("encoder"):
+            return self._encoder_impl(mel, Tm, t_full, tok_host, P)
+
+    def _encoder_impl(self, mel, Tm, t_full, tok_host, P):
+        """conv stem + 12 transformer layers + final LayerNorm with the length mask (modules.py:287-376) on frame-major
+        mel [B, Tm, n_mel].  t_full: the number of encoder tokens the reference would run (1500 for a 30 s padded call).
+        Returns hn [B, Tds*s, D] in the encode operand format, zero beyond each length (the zero-extended encoder output
+        the down-sampler reads), Tds."""
         B, dt, D = mel.shape[0], P.edt, P.D
         dev = mel.device
         Ttok = max(1, min(t_full, max(tok_host)))
@@ -383,44 +478,82 @@ class AudioCodec(nn.Module):
         s = P.stack
         tds_full = spec.cdiv(t_full, s)
         Tds = min(tds_full, spec.cdiv(Ttok, s) + 64)
-        # encoder output is exactly zero beyond each length (zero halves are a zero in split-f16 too)
-        hn = torch.zeros((B, Tds * s, ops._w(dt, D)), device=dev, dtype=dt)
-        ops.layernorm(h, P.enc_ln[0], P.enc_ln[1], 1e-5, B=B, t_in=Ttok, t_out=Tds * s, C_=D, lens=lens, out=hn)
+        # encoder output is exactly zero beyond each length: the LayerNorm kernel writes those rows as zeros
+        # (zero halves are a zero in split-f16 too), so no separate fill pass is needed
+        hn = ops.layernorm(h, P.enc_ln[0], P.enc_ln[1], 1e-5, B=B, t_in=Ttok, t_out=Tds * s, C_=D, lens=lens, out_dtype=dt)
+        return hn, Tds
+
+    def _downsample(self, hn, B, Tds, P):
+        with trace.stage("downsample"):
+            return self._downsample_impl(hn, B, Tds, P)
+
+    def _downsample_impl(self, hn, B, Tds, P):
+        """FrameStackDownConv (modules.py:519-550) on the zero-extended encoder output hn [B, Tds*s, D] (operand format).
+        Returns z [B, Tds, lat] f32."""
+        dt, s, D = P.edt, P.stack, P.D
         hd = self._mm(hn, P.inw, B * Tds, P.hid, s * D, lda=s * D, bias=P.inb)
         self._res_units(hd, P.down_units, B, Tds, P.hid, dt)
         z = self._mm(self._cast(hd, dt), P.tlw, B * Tds, P.lat, P.hid, lda=P.hid, bias=P.tlb)
-        return z.view(B, Tds, P.lat), Tds, [spec.cdiv(t, s) for t in tok_host]
+        return z.view(B, Tds, P.lat)
+
+    def _encode_mel(self, mel, Tm, t_full, tok_host, P):
+        """conv stem + encoder + down-sampler.  Returns z [B, Tds, lat] f32, Tds, latent lengths (host list)."""
+        hn, Tds = self._encoder(mel, Tm, t_full, tok_host, P)
+        z = self._downsample(hn, mel.shape[0], Tds, P)
+        return z, Tds, [spec.cdiv(t, P.stack) for t in tok_host]
 
     # Vocos receptive field: embed k7 (+-3) + 24 depthwise k7 (+-72) frames, ISTFT overlap +-2 frames (SURVEY.md 8a row V
     # measured -73 ... +74): frames computed this far beyond the kept ones make the kept samples bit-identical
     VOCOS_HALO_FRAMES = 80
 
-    def _decode_latent(self, zq, lat_host, B, T, P, keep_frames=None):
-        """up-sampler + decoder + Vocos on zq [B, T, lat] f32 (already masked). Returns wav [B, T*1280] f32, or
-        [B, keep_frames*160] when only the first keep_frames Vocos frames are wanted (long-form windows keep 2000
-        of their 3000 frames: the local-receptive-field vocoder then runs on 2000 + halo frames, SURVEY.md 8 f4)."""
-        dt, dev = P.ddt, zq.device
-        s, D = P.stack, P.Dd
+    def _upsample(self, zq, B, T, P):
+        with trace.stage("upsample"):
+            return self._upsample_impl(zq, B, T, P)
+
+    def _upsample_impl(self, zq, B, T, P):
+        """FrameStackUpConv (modules.py:601-631, not masked) on zq [B, T, lat] f32.  Returns x [B * s*T, D] f32: to_stacked
+        with re-ordered rows makes [B*T, s*D] the un-stacked [B, s*T, D] token stream."""
+        dt, s, D = P.ddt, P.stack, P.Dd
         h = self._mm(self._cast(zq, dt), P.flw, B * T, P.uhid, P.lat, lda=P.lat, bias=P.flb)
         self._res_units(h, P.up_units, B, T, P.uhid, dt)
-        # to_stacked with re-ordered rows: [B*T, s*D] is the un-stacked [B, s*T, D] token stream
         x = self._mm(self._cast(h, dt), P.tsw, B * T, s * D, P.uhid, lda=P.uhid, bias=P.tsb)
-        Tt = s * T
-        x = x.view(B * Tt, D)
-        lens = self._dev_ints([l * s for l in lat_host], dev)
+        return x.view(B * s * T, D)
+
+    def _decoder(self, x, lat_host, B, Tt, P):
+        with trace.stage("decoder"):
+            return self._decoder_impl(x, lat_host, B, Tt, P)
+
+    def _decoder_impl(self, x, lat_host, B, Tt, P):
+        """OmniAudioDecoder (modules.py:437-474): 12 layers (masked), LayerNorm + mask, deconv1 (k3, s2), deconv2 (k3),
+        crop to 2*Tt.  x [B*Tt, D] f32 (updated in place).  Returns mel [B, 2*Tt, 80] in the decode operand format."""
+        dt, dev, D = P.ddt, x.device, P.Dd
+        lens = self._dev_ints([l * P.stack for l in lat_host], dev)
         self._transformer(x, lens, B, Tt, P.dec_layers, P.Hd, dt)
         hn = ops.layernorm(x, P.dec_ln[0], P.dec_ln[1], 1e-5, B=B, t_in=Tt, C_=D, lens=lens, out_dtype=dt)
         y3 = self._mm(hn, P.d1w, B * Tt, 3 * D, D, lda=D)
         Tv = 2 * Tt
         d1 = ops.deconv_col2im(y3, P.d1b, B=B, T=Tt, C_=D, s=2, t_out=Tv + 1, out_dtype=dt)
-        mel = self._mm(d1, P.d2w, B * Tv, P.vin, D, lda=D, ldw=3 * D, bias=P.d2b, taps=3, pad=2, t_in=Tv + 1, t_out=Tv,
-                       out_dtype=dt)
+        return self._mm(d1, P.d2w, B * Tv, P.vin, D, lda=D, ldw=3 * D, bias=P.d2b, taps=3, pad=2, t_in=Tv + 1, t_out=Tv,
+                        out_dtype=dt).view(B, Tv, P.vin)
+
+    def _decode_latent(self, zq, lat_host, B, T, P, keep_frames=None):
+        """up-sampler + decoder + Vocos on zq [B, T, lat] f32 (already masked). Returns wav [B, T*1280] f32, or
+        [B, keep_frames*160] when only the first keep_frames Vocos frames are wanted (long-form windows keep 2000
+        of their 3000 frames: the local-receptive-field vocoder then runs on 2000 + halo frames, SURVEY.md 8 f4)."""
+        Tt = P.stack * T
+        x = self._upsample(zq, B, T, P)
+        mel = self._decoder(x, lat_host, B, Tt, P)
+        Tv = 2 * Tt
         if keep_frames is not None and keep_frames < Tv:
-            mel = mel.view(B, Tv, -1)[:, :keep_frames].contiguous()
+            mel = mel[:, :keep_frames].contiguous()
             Tv = keep_frames
         return self._vocos(mel, B, Tv, P)
 
     def _vocos(self, mel, B, Tv, P):
+        with trace.stage("vocos"):
+            return self._vocos_impl(mel, B, Tv, P)
+
+    def _vocos_impl(self, mel, B, Tv, P):
         """Vocos backbone + ISTFT head (modules.py:1492-1504, 1229-1248, 1053-1082, 831-886). mel [B, Tv, 80]."""
         dt, C, M = P.ddt, P.vdim, B * Tv
         x = self._mm(mel, P.emw, M, C, P.vin, lda=P.vin, ldw=7 * P.vin, bias=P.emb, taps=7, pad=3, t_in=Tv, t_out=Tv)
@@ -477,26 +610,32 @@ class AudioCodec(nn.Module):
         return out
 
     # ------------------------------------------------- reference entry points
+    @_on_model_device
     @torch.inference_mode()
     def inference_tokenize(self, x, input_lengths):
         """model.py:167-210. x (B, 1, T<=480000) on the device, input_lengths (B,).
         Returns zq (B, D, 375), codes (G, B, 375) int32, codes_lengths (B,) int64."""
-        P = self._packed()
-        n_host = [min(int(v), spec.CHUNK_SAMPLES) for v in (input_lengths.tolist() if torch.is_tensor(input_lengths) else input_lengths)]
         B = x.shape[0]
         wav = x.reshape(B, -1).to(torch.float32)
+        # the reference slices xi[:, :x_len] (model.py:180): a length beyond the row is the row
+        n_host = [min(int(v), spec.CHUNK_SAMPLES, wav.shape[1]) for v in
+                  (input_lengths.tolist() if torch.is_tensor(input_lengths) else input_lengths)]
         if wav.stride(-1) != 1:
             wav = wav.contiguous()
         dev = wav.device
         n_dev = self._dev_ints(n_host, dev)
-        mel, Tm = self._logmel(wav, n_dev, n_host, P)
         tok = [spec.token_len(n) for n in n_host]
-        z, Tds, lat = self._encode_mel(mel, Tm, spec.MEL_FRAMES // 2, tok, P)
-        t_pad = spec.cdiv(spec.MEL_FRAMES // 2, P.stack)  # 375: the reference always returns the padded length
-        lat_dev = self._dev_ints(lat, dev)
-        zq, codes = ops.fsq_encode(z, P.lat, lat_dev, P.fsq, B=B, T=Tds, t_pad=t_pad, G=self.num_groups)
-        return {"zq": zq.transpose(1, 2), "codes": codes, "codes_lengths": lat_dev.long()}
 
+        def run(P):
+            mel, Tm = self._logmel(wav, n_dev, n_host, P)
+            z, Tds, lat = self._encode_mel(mel, Tm, spec.MEL_FRAMES // 2, tok, P)
+            t_pad = spec.cdiv(spec.MEL_FRAMES // 2, P.stack)  # 375: the reference always returns the padded length
+            lat_dev = self._dev_ints(lat, dev)
+            zq, codes = ops.fsq_encode(z, P.lat, lat_dev, P.fsq, B=B, T=Tds, t_pad=t_pad, G=self.num_groups)
+            return {"zq": zq.transpose(1, 2), "codes": codes, "codes_lengths": lat_dev.long()}
+        return self._guarded_encode(run)
+
+    @_on_model_device
     @torch.inference_mode()
     def inference_detokenize(self, codes, codes_lengths, _keep_samples=None):
         """model.py:212-242. codes (G, B, T) integer, codes_lengths (B,). Returns y (B, 1, T*1280), output_length.
@@ -520,17 +659,17 @@ class AudioCodec(nn.Module):
     max_rows_per_call = 64
     trim_vocos = True  # decode(): run Vocos only on the kept frames (+ halo) of each window; bit-identical output
 
-    def _stack(self, tensors, lens, dev, dtype):
-        """list of 1-D tensors -> zero-padded [B, max(len)] on dev.  Device-resident 4-byte rows (the normal case) are
-        assembled by one gather kernel from an uploaded address list instead of one copy per utterance."""
-        L = max(max(lens), 1)
+    def _stack(self, tensors, lens, dev, dtype, min_len=0):
+        """list of 1-D tensors -> zero-padded [B, max(len, min_len)] on dev.  Device-resident 4-byte rows (the normal case)
+        are assembled by one gather kernel from an uploaded address list instead of one copy per utterance."""
+        L = max(max(lens), 1, int(min_len))
         if (dev.type == "cuda" and dtype in (torch.float32, torch.int32) and len(tensors) <= 65535
                 and all(t.device == dev and t.dtype == dtype and t.is_contiguous() and t.data_ptr() % 4 == 0
                         for t in tensors)):
             ptrs = self._dev_ints([t.data_ptr() for t in tensors], dev, torch.int64, cache_it=False)
             nbytes = self._dev_ints([4 * n for n in lens], dev, torch.int64)
             return ops.gather_rows(ptrs, nbytes, len(tensors), L, dtype, dev)
-        if len(set(lens)) == 1 and lens[0] > 0 and all(t.device == dev and t.dtype == dtype for t in tensors):
+        if len(set(lens)) == 1 and lens[0] == L and all(t.device == dev and t.dtype == dtype for t in tensors):
             return torch.stack([t.reshape(-1) for t in tensors])
         out = torch.zeros(len(tensors), L, device=dev, dtype=dtype)
         for i, t in enumerate(tensors):
@@ -538,6 +677,7 @@ class AudioCodec(nn.Module):
                 out[i, : lens[i]] = t.reshape(-1)
         return out
 
+    @_on_model_device
     @torch.inference_mode()
     def encode(self, wav_list, overlap_seconds=10, device=torch.device("cuda")):
         """model.py:244-308: 30 s windows every (30 - overlap) s, keep the first 250 codes of each window,
@@ -551,7 +691,7 @@ class AudioCodec(nn.Module):
             return {"codes_list": []}
         n = [int(w.shape[-1]) if w.dim() else 0 for w in wav_list]
         L = max(n)
-        dev = self._buffers_device() if device is None else torch.device(device)
+        dev = self._resolve_device(device)
         wav = self._stack(wav_list, n, dev, torch.float32)
         wins = []
         for c in range(spec.cdiv(L, dur) if L else 0):
@@ -582,6 +722,7 @@ class AudioCodec(nn.Module):
         allc = torch.cat(parts, dim=-1) if len(parts) > 1 else parts[0]
         return {"codes_list": [allc[:, i, : n[i] // rate] for i in range(B)]}
 
+    @_on_model_device
     @torch.inference_mode()
     def decode(self, codes_list, overlap_seconds=10, device=torch.device("cuda"), pad_to_length=None):
         """model.py:310-373: 375-code windows every 250 codes, keep the first 320000 samples of each,
@@ -598,7 +739,7 @@ class AudioCodec(nn.Module):
             return {"syn_wav_list": []}
         n = [int(c.shape[-1]) for c in codes_list]
         L = max(max(n), int(pad_to_length or 0))
-        dev = self._buffers_device() if device is None else torch.device(device)
+        dev = self._resolve_device(device)
         if L == 0:
             return {"syn_wav_list": [torch.zeros(0, device=dev) for _ in range(B)]}
         G = self.num_groups
@@ -649,24 +790,28 @@ class AudioCodec(nn.Module):
         wav = torch.cat([parts[c] for c in order], dim=-1) if len(order) > 1 else parts[order[0]]
         return {"syn_wav_list": [wav[i, : n[i] * self.decoder_upsample_rate] for i in range(B)]}
 
+    @_on_model_device
     @torch.inference_mode()
     def forward(self, batch):
         """model.py:112-165: mel (B, n_mel, T) + mel_lens -> {'reconstructed_audio' (B,1,T_audio), 'audio_lengths'}.
         No 30 s padding and no chunking; the un-masked up-sampler sees the whole padded length."""
-        P = self._packed()
         mel_in, ml = batch["mel_features"], batch["mel_lens"]
         B, _, T = mel_in.shape
         ml_host = [int(v) for v in ml.tolist()]
-        mel = mel_in.to(torch.float32).transpose(1, 2).contiguous()
-        mel = self._cast(mel, P.c1dt)
+        mel32 = mel_in.to(torch.float32).transpose(1, 2).contiguous()
+        dev = mel32.device
         t_full = (T - 1) // 2 + 1  # Conv1d(k3, s2, p1) output length
         tok = [m // 2 for m in ml_host]
-        # the trimmed stem needs frames up to 2*max(tok): the given T is the true right boundary
-        z, Tds, lat = self._encode_mel(mel, T, t_full, tok, P)
-        dev = mel.device
-        t_lat = spec.cdiv(t_full, P.stack)
-        lat_dev = torch.tensor(lat, dtype=torch.int32, device=dev)
-        zq, _ = ops.fsq_encode(z, P.lat, lat_dev, P.fsq, B=B, T=Tds, t_pad=t_lat, G=self.num_groups)
+        t_lat = spec.cdiv(t_full, self.generator_params["downsample"]["stack_factor"])
+
+        def run(P):
+            # the trimmed stem needs frames up to 2*max(tok): the given T is the true right boundary
+            z, Tds, lat = self._encode_mel(self._cast(mel32, P.c1dt), T, t_full, tok, P)
+            lat_dev = self._dev_ints(lat, dev)
+            zq, _ = ops.fsq_encode(z, P.lat, lat_dev, P.fsq, B=B, T=Tds, t_pad=t_lat, G=self.num_groups)
+            return zq, lat, lat_dev
+        zq, lat, lat_dev = self._guarded_encode(run)
+        P = self._packed()
         wav = self._decode_latent(zq, lat, B, t_lat, P)
         return {"reconstructed_audio": wav[:, None, :],
                 "audio_lengths": lat_dev.long() * (P.stack * 2 * self.generator_params["vocos"]["hop_size"])}

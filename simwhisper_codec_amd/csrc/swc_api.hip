@@ -11,7 +11,15 @@ void swc_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int swc_version(void) { return 110; }  // 1.10: + fp8 mode, swc_cast_fp8, swc_gather_rows
+// per calling thread: where the producers of split-f16 / fp8 activations report clipping (device memory, caller-owned)
+static thread_local unsigned* g_sat = nullptr;
+unsigned* swc_sat_counter() { return g_sat; }
+extern "C" int swc_set_saturation_counter(uint32_t* dev_counters) {
+    g_sat = dev_counters;
+    return SWC_OK;
+}
+
+extern "C" int swc_version(void) { return 200; }  // 2.00: + swc_set_saturation_counter, swc_convnext_mlp, packed layouts
 
 extern "C" const char* swc_last_error(void) { return g_err; }
 

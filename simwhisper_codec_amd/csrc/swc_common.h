@@ -42,9 +42,19 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t x) {
     return __uint_as_float(((unsigned)x) << 16);
 }
 
+// Saturation accounting (swc_set_saturation_counter in swc.h).  Producers of split-f16 / fp8 ACTIVATIONS keep the
+// largest |scaled value| they converted in a register (one v_max per element, |x| is a free source modifier) and add
+// one to the caller's device counter when it exceeded the format's range: the conversion then clipped.
+#define SWC_F16S_LIMIT 65504.0f
+#define SWC_FP8_LIMIT 448.0f
+unsigned* swc_sat_counter();  // host: the calling thread's counter pair {split-f16, fp8} (device memory) or nullptr
+__device__ __forceinline__ void sat_commit(unsigned* sat, int which, float amax, float limit) {
+    if (sat != nullptr && amax > limit) atomicAdd(sat + which, 1u);
+}
+
 // split one scaled f32 into (hi, lo) halves; saturates instead of overflowing to inf
 __device__ __forceinline__ void f16s_split(float v, unsigned short& hi, unsigned short& lo) {
-    v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+    v = fminf(fmaxf(v, -SWC_F16S_LIMIT), SWC_F16S_LIMIT);
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)(v - (float)h);
     hi = *reinterpret_cast<const unsigned short*>(&h);
@@ -61,6 +71,16 @@ __device__ __forceinline__ void f16s_store4(unsigned short* row, long k, float a
     *reinterpret_cast<uint2*>(p + 32) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
 }
 
+// the same with range tracking
+__device__ __forceinline__ void f16s_split(float v, unsigned short& hi, unsigned short& lo, float& amax) {
+    amax = fmaxf(amax, fabsf(v));
+    f16s_split(v, hi, lo);
+}
+__device__ __forceinline__ void f16s_store4(unsigned short* row, long k, float a, float b, float c, float d, float& amax) {
+    amax = fmaxf(fmaxf(amax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
+    f16s_store4(row, k, a, b, c, d);
+}
+
 // 4 floats -> 4 e4m3 bytes (v_cvt_pk_fp8_f32, RNE), saturating at the largest finite value
 __device__ __forceinline__ unsigned fp8_pack4(float a, float b, float c, float d) {
     a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
@@ -69,6 +89,11 @@ __device__ __forceinline__ unsigned fp8_pack4(float a, float b, float c, float d
     w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
     w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
     return (unsigned)w;
+}
+
+__device__ __forceinline__ unsigned fp8_pack4(float a, float b, float c, float d, float& amax) {
+    amax = fmaxf(fmaxf(amax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
+    return fp8_pack4(a, b, c, d);
 }
 
 template <typename T>

@@ -21,6 +21,18 @@
 // CONTIGUOUS output columns 16fh + 4j + e — 64-byte vector stores, full lines per row across fh.
 #include "swc_common.h"
 
+// Geometry overrides for A/B measurements exist only in tuning builds (-DSWC_TUNING, tools/build_variant.sh): the
+// shipped library reads no environment variable and keeps no mutable process-wide state.
+static inline int tuning_env(const char* name, int dflt = 0) {
+#ifdef SWC_TUNING
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 namespace {
 
 
@@ -78,7 +90,7 @@ struct GemmP {
     int act;
     float alpha, out_scale;
     int band;        // tile-order band height (row panels), see the kernel
-    int dbg;         // diagnostics only (SWC_GEMM_DBG): 1 = skip LDS-DMA, 2 = skip barriers (wrong results, timing only)
+    unsigned* sat;   // saturation counter pair of the calling thread (swc_set_saturation_counter) or nullptr
     int kc_per_tap;  // ceil(K / BK)
     int n_tiles_n, n_tiles_m;
 };
@@ -96,6 +108,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
     float bv[16], gv[16];
+    float amax = 0.f;
+    (void)amax;
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         const int col = col0 + c;
@@ -129,7 +143,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
                 unsigned short* rowp = reinterpret_cast<unsigned short*>(p.C) + (long)row * p.ldc * 2;
                 unsigned short h[16], l[16];
 #pragma unroll
-                for (int c = 0; c < 16; ++c) f16s_split(v[c] * p.out_scale, h[c], l[c]);
+                for (int c = 0; c < 16; ++c) f16s_split(v[c] * p.out_scale, h[c], l[c], amax);
                 unsigned short* hp = rowp + f16s_col(col0);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
@@ -159,10 +173,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
             } else if constexpr (sizeof(OutT) == 1) {
                 const float os = p.out_scale;
                 uint4 u;
-                u.x = fp8_pack4(v[0] * os, v[1] * os, v[2] * os, v[3] * os);
-                u.y = fp8_pack4(v[4] * os, v[5] * os, v[6] * os, v[7] * os);
-                u.z = fp8_pack4(v[8] * os, v[9] * os, v[10] * os, v[11] * os);
-                u.w = fp8_pack4(v[12] * os, v[13] * os, v[14] * os, v[15] * os);
+                u.x = fp8_pack4(v[0] * os, v[1] * os, v[2] * os, v[3] * os, amax);
+                u.y = fp8_pack4(v[4] * os, v[5] * os, v[6] * os, v[7] * os, amax);
+                u.z = fp8_pack4(v[8] * os, v[9] * os, v[10] * os, v[11] * os, amax);
+                u.w = fp8_pack4(v[12] * os, v[13] * os, v[14] * os, v[15] * os, amax);
                 *reinterpret_cast<uint4*>(cp) = u;
             } else {
 #pragma unroll
@@ -182,11 +196,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
                 if (col >= p.N) continue;
                 float x = v[c];
                 if (p.residual) x += p.residual[(long)row * p.ldr + col];
-                if constexpr (__is_same(OutT, fp8_t)) x *= p.out_scale;
+                if constexpr (__is_same(OutT, fp8_t)) { x *= p.out_scale; amax = fmaxf(amax, fabsf(x)); }
                 if constexpr (!__is_same(OutT, f16s_t)) store_out<OutT>(C + (long)row * p.ldc + col, x);
             }
         }
     }
+    if constexpr (__is_same(OutT, f16s_t)) sat_commit(p.sat, 0, amax, SWC_F16S_LIMIT);
+    if constexpr (__is_same(OutT, fp8_t)) sat_commit(p.sat, 1, amax, SWC_FP8_LIMIT);
 }
 
 // PLAIN: one tap, K a multiple of the slice, no stride / padding / row remap — the hot GEMMs.  A separate
@@ -307,7 +323,6 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     auto stage_slice = [&](int kt, int stage) {
         const unsigned sa = smem_base + stage * STAGE_BYTES + wave_u * 1024;  // one wave-instruction = 1 KiB of rows
         const unsigned sb = sa + A_BYTES;
-        if (p.dbg & 1) return;
         if constexpr (PLAIN) {
             const long koff = (long)kt * ROW_BYTES;
             const char* ab = a_base + koff;
@@ -470,8 +485,7 @@ int launch_k(GemmP p, hipStream_t s) {
     p.n_tiles_n = (p.N + BN - 1) / BN;
     p.n_tiles_m = (p.M + BM - 1) / BM;
     {
-        static int forced = -1;
-        if (forced < 0) forced = getenv("SWC_GEMM_BAND") ? atoi(getenv("SWC_GEMM_BAND")) : 0;
+        const int forced = tuning_env("SWC_GEMM_BAND");
         p.band = forced > 0 ? forced : (p.n_tiles_n >= 12 ? 4 : 1);
     }
     const long nwg = (long)p.n_tiles_n * p.n_tiles_m;
@@ -482,8 +496,7 @@ int launch_k(GemmP p, hipStream_t s) {
     auto kern = gemm_kernel<MODE, OutT, MT, WM, WN, PLAIN, RB>;
     if (LDS > 64 * 1024) SWC_ENABLE_LDS(kern, LDS, "swc_gemm");
     // persistent grid: one workgroup per CU for the 8-wave geometries, two for the 4-wave one (256 CUs)
-    static int persist = -1;
-    if (persist < 0) persist = getenv("SWC_GEMM_NOPERSIST") ? 0 : 1;
+    const int persist = tuning_env("SWC_GEMM_NOPERSIST") ? 0 : 1;
     const long slots = 256L * (WM * WN == 4 ? 2 : 1);
     const long grid = (persist && nwg > slots) ? slots : nwg;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), LDS, s, p);
@@ -501,15 +514,8 @@ int launch(GemmP p, hipStream_t s) {
 
 }  // namespace
 
-// SWC_GEMM_TILE=128|256 overrides the geometry choice (benchmarking only).
-static int tile_override() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("SWC_GEMM_TILE");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
+// SWC_GEMM_TILE=128|256 overrides the geometry choice (tuning builds only).
+static int tile_override() { return tuning_env("SWC_GEMM_TILE"); }
 
 extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     SWC_CHECK_ARG(a != nullptr, "swc_gemm: null args");
@@ -556,11 +562,7 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     const int bk = bf ? 64 : (f8 ? 128 : 32);
     p.kc_per_tap = (a->K + bk - 1) / bk;
     p.n_tiles_n = p.n_tiles_m = 0;
-    {
-        static int dbg = -1;
-        if (dbg < 0) dbg = getenv("SWC_GEMM_DBG") ? atoi(getenv("SWC_GEMM_DBG")) : 0;
-        p.dbg = dbg;
-    }
+    p.sat = swc_sat_counter();
     hipStream_t s = (hipStream_t)stream;
     // geometry: the 256x256 / 8-wave tile pays off when its grid still fills the 256 CUs
     const long big_tiles = (long)((a->M + 255) / 256) * ((a->N + 255) / 256);
@@ -577,8 +579,7 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     // 189 tiles of 256 rows leave a quarter of the chip idle, 252 tiles of 192 rows fill it in one round.
     int mt = 8;
     if (((bf || f8) && big) || (fs && a->N >= 256 && big_tiles >= 96)) {
-        static int forced = -1;
-        if (forced < 0) forced = getenv("SWC_GEMM_MT") ? atoi(getenv("SWC_GEMM_MT")) : 0;
+        const int forced = tuning_env("SWC_GEMM_MT");
         const long ntn = (a->N + 255) / 256;
         double best = 1e30;
         for (int cand : {8, 6, 4}) {
@@ -590,8 +591,7 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     }
     // small grids: when the 128 x 128 tiling leaves CU slots empty (4-wave workgroups, two per CU), 64-row tiles double
     // the workgroup count (down- / up-sampler k7 convs: 6048 x 512 outputs = 192 tiles on 512 slots)
-    static int small_env = -1;
-    if (small_env < 0) small_env = getenv("SWC_GEMM_SMALL") ? atoi(getenv("SWC_GEMM_SMALL")) : 1;
+    const int small_env = tuning_env("SWC_GEMM_SMALL", 1);
     const long tiles128 = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
     const bool half_rows = small_env && tiles128 < 384 && a->M >= 512;
     if (f8) {

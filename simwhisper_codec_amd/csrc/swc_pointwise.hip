@@ -40,19 +40,25 @@ __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, floa
 // store 4 consecutive columns col..col+3 of a row; `row` points at the row start in OutT units
 // (split-f16 rows are addressed in halves: 2 per logical column)
 template <typename OutT>
-__device__ __forceinline__ void store_row4(OutT* row, int col, float a, float b, float c, float d) {
+__device__ __forceinline__ void store_row4(OutT* row, int col, float a, float b, float c, float d, float& amax) {
     if constexpr (__is_same(OutT, fp8_t)) {
         *reinterpret_cast<unsigned*>(row + col) = fp8_pack4(a * SWC_FP8_ACT_SCALE, b * SWC_FP8_ACT_SCALE,
-                                                            c * SWC_FP8_ACT_SCALE, d * SWC_FP8_ACT_SCALE);
+                                                            c * SWC_FP8_ACT_SCALE, d * SWC_FP8_ACT_SCALE, amax);
     } else if constexpr (__is_same(OutT, f16s_t)) {
         f16s_store4(reinterpret_cast<unsigned short*>(row), col, a * SWC_F16S_ACT_SCALE, b * SWC_F16S_ACT_SCALE,
-                    c * SWC_F16S_ACT_SCALE, d * SWC_F16S_ACT_SCALE);
+                    c * SWC_F16S_ACT_SCALE, d * SWC_F16S_ACT_SCALE, amax);
     } else {
         store4<OutT>(row + col, a, b, c, d);
     }
 }
 template <typename OutT>
 __device__ __forceinline__ long row_units(long C) { return __is_same(OutT, f16s_t) ? 2 * C : C; }
+// range of the output format of a producer (infinite for f32 / bf16) and its slot in the saturation counter pair
+template <typename OutT>
+__device__ __forceinline__ void sat_commit_out(unsigned* sat, float amax) {
+    if constexpr (__is_same(OutT, f16s_t)) sat_commit(sat, 0, amax, SWC_F16S_LIMIT);
+    if constexpr (__is_same(OutT, fp8_t)) sat_commit(sat, 1, amax, SWC_FP8_LIMIT);
+}
 
 // ------------------------------------------------------------------ LayerNorm
 constexpr int LN_MAXV = 8;  // float4 per lane => C <= 2048
@@ -62,7 +68,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bia,
                                                         const int* __restrict__ lens, long rows, int tw,
-                                                        int t_in, int t_out, int C, float eps) {
+                                                        int t_in, int t_out, int C, float eps, unsigned* sat) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
@@ -70,10 +76,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float* xr = x + ((long)b * t_in + t) * C;
     OutT* yr = y + ((long)b * t_out + t) * row_units<OutT>(C);
     const int nv = C >> 2;  // float4 count
-    if (lens && t >= lens[b]) {
-        for (int i = lane; i < nv; i += 64) store_row4<OutT>(yr, 4 * i, 0.f, 0.f, 0.f, 0.f);
+    if (t >= t_in || (lens && t >= lens[b])) {  // masked rows, and the zero extension beyond the input (t_out > t_in)
+        float z_ = 0.f;
+        for (int i = lane; i < nv; i += 64) store_row4<OutT>(yr, 4 * i, 0.f, 0.f, 0.f, 0.f, z_);
         return;
     }
+    float amax = 0.f;
     float4 v[LN_MAXV];
     float s = 0.f;
 #pragma unroll
@@ -103,9 +111,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             const float4 ww = *reinterpret_cast<const float4*>(w + 4 * i);
             const float4 bb = *reinterpret_cast<const float4*>(bia + 4 * i);
             store_row4<OutT>(yr, 4 * i, (v[k].x - mean) * rstd * ww.x + bb.x, (v[k].y - mean) * rstd * ww.y + bb.y,
-                             (v[k].z - mean) * rstd * ww.z + bb.z, (v[k].w - mean) * rstd * ww.w + bb.w);
+                             (v[k].z - mean) * rstd * ww.z + bb.z, (v[k].w - mean) * rstd * ww.w + bb.w, amax);
         }
     }
+    sat_commit_out<OutT>(sat, amax);
 }
 
 // ------------------------------------------------- depthwise k7 conv + LayerNorm
@@ -271,7 +280,7 @@ template <typename OutT>
 __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__ x, OutT* __restrict__ y,
                                                        const float* __restrict__ alpha,
                                                        const float* __restrict__ beta, Filt12 F, int T,
-                                                       int C) {
+                                                       int C, unsigned* sat) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     const int b = blockIdx.z;
@@ -327,6 +336,7 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < 6; ++k) pair_clamped(t0 - 3 + k, A0[k], A1[k]);
     const int tend = (t0 + SN_TS < T) ? t0 + SN_TS : T;
+    float amax = 0.f;
     for (int t = t0; t < tend; ++t) {
         pair_clamped(t + 3, A0[6], A1[6]);
         // out[t] = sum_k a[2t-5+k] f[k]; 2t-5 = 2(t-3)+1 -> starts at A1[0]
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
         }
         if constexpr (__is_same(OutT, f16s_t)) {
             unsigned short hi, lo;
-            f16s_split(o * SWC_F16S_ACT_SCALE, hi, lo);
+            f16s_split(o * SWC_F16S_ACT_SCALE, hi, lo, amax);
             unsigned short* rp = reinterpret_cast<unsigned short*>(yb) + (long)t * 2 * C + f16s_col(c);
             rp[0] = hi;
             rp[32] = lo;
@@ -349,6 +359,7 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
 #pragma unroll
         for (int k = 0; k < 6; ++k) { A0[k] = A0[k + 1]; A1[k] = A1[k + 1]; }
     }
+    sat_commit_out<OutT>(sat, amax);
     (void)T2;
 }
 
@@ -403,7 +414,12 @@ __global__ void fsq_decode_kernel(const long long* __restrict__ codes, float* __
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int half = kLevels[d] / 2;
-            const long long nn = (idx / base) % kLevels[d];
+            // torch's `//` and `%` (quantizer.py:214-216) round towards -inf: identical to C for valid codes, and for
+            // out-of-range / negative ones the same wrapped level instead of C's truncation
+            long long qd = idx / base;
+            if (idx % base < 0) --qd;
+            long long nn = qd % kLevels[d];
+            if (nn < 0) nn += kLevels[d];
             q[d] = __fdiv_rn((float)(nn - half), (float)half);
             base *= kLevels[d];
         }
@@ -602,7 +618,7 @@ __global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict
 }
 
 template <typename InT>
-__global__ void cast_fp8_kernel(const InT* __restrict__ x, unsigned* __restrict__ y, long n4, float scale) {
+__global__ void cast_fp8_kernel(const InT* __restrict__ x, unsigned* __restrict__ y, long n4, float scale, unsigned* sat) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 4 elements
     if (i >= n4) return;
     float a, b, c, d;
@@ -614,18 +630,22 @@ __global__ void cast_fp8_kernel(const InT* __restrict__ x, unsigned* __restrict_
         a = bf16_to_f32((bf16_t)(v.x & 0xffff)); b = bf16_to_f32((bf16_t)(v.x >> 16));
         c = bf16_to_f32((bf16_t)(v.y & 0xffff)); d = bf16_to_f32((bf16_t)(v.y >> 16));
     }
-    y[i] = fp8_pack4(a * scale, b * scale, c * scale, d * scale);
+    float amax = 0.f;
+    y[i] = fp8_pack4(a * scale, b * scale, c * scale, d * scale, amax);
+    sat_commit(sat, 1, amax, SWC_FP8_LIMIT);
 }
 
 __global__ void cast_f16s_kernel(const float* __restrict__ x, long ldx, unsigned short* __restrict__ y, long rows,
-                                 int K, float scale) {
+                                 int K, float scale, unsigned* sat) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one thread per 4 logical columns
     const int k4 = K >> 2;
     if (i >= rows * k4) return;
     const long r = i / k4;
     const int k = (int)(i - r * k4) * 4;
     const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + k);
-    f16s_store4(y + r * 2L * K, k, v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+    float amax = 0.f;
+    f16s_store4(y + r * 2L * K, k, v.x * scale, v.y * scale, v.z * scale, v.w * scale, amax);
+    sat_commit(sat, 0, amax, SWC_F16S_LIMIT);
 }
 
 inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
@@ -649,23 +669,23 @@ extern "C" int swc_layernorm(const float* x, void* y, const float* w, const floa
     SWC_CHECK_ARG(y_dtype == SWC_F32 || y_dtype == SWC_BF16 || y_dtype == SWC_F16S || y_dtype == SWC_FP8,
                   "swc_layernorm: bad dtype");
     SWC_CHECK_ARG(y_dtype != SWC_F16S || C % 32 == 0, "swc_layernorm: split-f16 output needs C % 32 == 0");
-    const int tw = t_in < t_out ? t_in : t_out;
+    const int tw = t_out;  // every output row is written: rows beyond t_in are zeros
     const long rows = (long)B * tw;
     if (rows <= 0) return SWC_OK;
     hipStream_t s = (hipStream_t)stream;
     if (y_dtype == SWC_FP8) {
         hipLaunchKernelGGL(layernorm_kernel<fp8_t>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (fp8_t*)y, w, b, lens, rows,
-                           tw, t_in, t_out, C, eps);
+                           tw, t_in, t_out, C, eps, swc_sat_counter());
         SWC_CHECK_LAUNCH("swc_layernorm");
         return SWC_OK;
     }
     OUT_DISPATCH3(y_dtype,
                   hipLaunchKernelGGL(layernorm_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (float*)y, w,
-                                     b, lens, rows, tw, t_in, t_out, C, eps),
+                                     b, lens, rows, tw, t_in, t_out, C, eps, swc_sat_counter()),
                   hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (bf16_t*)y,
-                                     w, b, lens, rows, tw, t_in, t_out, C, eps),
+                                     w, b, lens, rows, tw, t_in, t_out, C, eps, swc_sat_counter()),
                   hipLaunchKernelGGL(layernorm_kernel<f16s_t>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (f16s_t*)y,
-                                     w, b, lens, rows, tw, t_in, t_out, C, eps));
+                                     w, b, lens, rows, tw, t_in, t_out, C, eps, swc_sat_counter()));
     SWC_CHECK_LAUNCH("swc_layernorm");
     return SWC_OK;
 }
@@ -678,7 +698,7 @@ static int launch_dwconv7_ln(const float* x, void* y, const float* w, const floa
     if (lds > 48 * 1024) SWC_ENABLE_LDS(kern, 160 * 1024, "swc_dwconv7_ln");
     const int nst = (T + S - 1) / S, nstrips = nst * B;
     // resident workgroups: LDS-limited per CU, 256 CUs; each walks nstrips / grid strips
-    static const int wgs = getenv("SWC_DW_WGS") ? atoi(getenv("SWC_DW_WGS")) : 0;
+    const int wgs = 0;
     const int fit = 160 * 1024 / lds;
     const int slots = 256 * (wgs > 0 ? wgs : (fit > 2 ? 2 : fit));  // <= 2 waves per SIMD by registers
     const int per = (nstrips + slots - 1) / slots;           // consecutive strips per workgroup
@@ -709,9 +729,8 @@ extern "C" int swc_dwconv7_ln(const float* x, void* y, const float* w, const flo
                      : launch_dwconv7_ln<float, NK_, S_, false>(x, y, w, bias, ln_w, ln_b, B, T, C, eps, s);      \
     } while (0)
     // strips of 16 frames: (16+6) rows of LDS per workgroup, two workgroups per CU (register-limited)
-    static const int forced = getenv("SWC_DW_STRIP") ? atoi(getenv("SWC_DW_STRIP")) : 0;
     if (C <= 256) { DW_GO(1, 32); }
-    else if (C <= 512) { if (forced == 32) { DW_GO(2, 32); } else { DW_GO(2, 16); } }
+    else if (C <= 512) { DW_GO(2, 16); }
     else { DW_GO(4, 16); }
 #undef DW_GO
     if (rc != SWC_OK) return rc;
@@ -732,9 +751,9 @@ extern "C" int swc_snake_aa(const float* x, void* y, const float* alpha, const f
     dim3 grid(nblk(C, 256), nblk(T, SN_TS), B);
     hipStream_t s = (hipStream_t)stream;
     OUT_DISPATCH3(y_dtype,
-                  hipLaunchKernelGGL(snake_aa_kernel<float>, grid, dim3(256), 0, s, x, (float*)y, alpha, beta, F, T, C),
-                  hipLaunchKernelGGL(snake_aa_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)y, alpha, beta, F, T, C),
-                  hipLaunchKernelGGL(snake_aa_kernel<f16s_t>, grid, dim3(256), 0, s, x, (f16s_t*)y, alpha, beta, F, T, C));
+                  hipLaunchKernelGGL(snake_aa_kernel<float>, grid, dim3(256), 0, s, x, (float*)y, alpha, beta, F, T, C, swc_sat_counter()),
+                  hipLaunchKernelGGL(snake_aa_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)y, alpha, beta, F, T, C, swc_sat_counter()),
+                  hipLaunchKernelGGL(snake_aa_kernel<f16s_t>, grid, dim3(256), 0, s, x, (f16s_t*)y, alpha, beta, F, T, C, swc_sat_counter()));
     SWC_CHECK_LAUNCH("swc_snake_aa");
     return SWC_OK;
 }
@@ -879,7 +898,7 @@ extern "C" int swc_cast_f32_f16s(const float* x, int64_t ldx, void* y, int64_t r
                   "swc_cast_f32_f16s: K=%d must be a multiple of 32, rows 16-byte aligned", K);
     if (rows <= 0) return SWC_OK;
     hipLaunchKernelGGL(cast_f16s_kernel, dim3(nblk(rows * (K / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx,
-                       (unsigned short*)y, (long)rows, K, scale == 0.0f ? 1.0f : scale);
+                       (unsigned short*)y, (long)rows, K, scale == 0.0f ? 1.0f : scale, swc_sat_counter());
     SWC_CHECK_LAUNCH("swc_cast_f32_f16s");
     return SWC_OK;
 }
@@ -946,10 +965,10 @@ extern "C" int swc_cast_fp8(const void* x, int32_t x_dtype, void* y, int64_t n, 
     const long n4 = n / 4;
     if (x_dtype == SWC_F32)
         hipLaunchKernelGGL(cast_fp8_kernel<float>, dim3(nblk(n4, 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const float*)x, (unsigned*)y, n4, scale);
+                           (const float*)x, (unsigned*)y, n4, scale, swc_sat_counter());
     else
         hipLaunchKernelGGL(cast_fp8_kernel<bf16_t>, dim3(nblk(n4, 256)), dim3(256), 0, (hipStream_t)stream,
-                           (const bf16_t*)x, (unsigned*)y, n4, scale);
+                           (const bf16_t*)x, (unsigned*)y, n4, scale, swc_sat_counter());
     SWC_CHECK_LAUNCH("swc_cast_fp8");
     return SWC_OK;
 }

@@ -1,13 +1,18 @@
-"""Utterance-level data parallelism over the GPUs of one node.
+"""Utterance-level data parallelism over the GPUs of one node (BASELINE.json configs[3]).
 
-One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" on CPU
-for tests).  The path has no exchange step: utterances are independent, so rank 0 fans the
-audio out with point-to-point sends (its 7 xGMI links work concurrently, nothing is
-reduced), every rank runs the unchanged single-GPU codec on its shard, and codes /
-waveforms come back the same way.  The only global quantity is the decode padding length:
-the reference's un-masked up-sampler / Vocos make a short utterance depend on the longest one
-in its batch, so the global maximum code length is shared (one integer) and every shard pads
-to it — sharded results are then identical to the single-GPU batch.
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI; "gloo" on CPU for tests).  The path has no
+exchange step: utterances are independent, so rank 0 scatters the audio with point-to-point sends grouped into one
+RCCL group call (its 7 xGMI links work concurrently, nothing is reduced, no ring), every rank runs the unchanged
+single-GPU codec on its shard, and codes / waveforms are gathered the same way.  This replaces the reference's serial
+batch loop (inference.py:38-64) for batches larger than one GPU's share.
+
+  * Shapes travel as ONE int64 tensor broadcast (count, then lengths) — no pickling, no object collectives.
+  * Rank 0 assembles the padded [B, L] batch once (one gather kernel) and sends each rank its ROW SLICE of that
+    buffer: no per-shard concatenation, no staging copy.  Receivers use row views of what arrives.
+  * The only global quantity is the decode padding length: the reference's un-masked up-sampler / Vocos make a short
+    utterance depend on the longest one of its batch (model.py:327-333), so shards pad to the global maximum code
+    length and sharded results equal the single-GPU batch bit for bit.
+  * encode_decode(): the gather of the codes (tiny) is posted before the local decode starts and completes under it.
 """
 import torch
 import torch.distributed as dist
@@ -36,6 +41,18 @@ def partition(weights, world):
     return bounds
 
 
+class _Pending:
+    """Outstanding point-to-point work + the buffers it fills."""
+
+    def __init__(self, works, bufs):
+        self.works, self.bufs = works, bufs
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        return self.bufs
+
+
 class DataParallelCodec:
     """Wraps a codec object (AudioCodec surface: encode/decode returning the reference's dicts)."""
 
@@ -47,98 +64,192 @@ class DataParallelCodec:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
 
-    # ---- point-to-point fan-out / fan-in of flat buffers
-    def _fan_out(self, flats, sizes, dtype):
-        """rank 0: flats[r] is the 1-D tensor for rank r.  Returns this rank's tensor."""
+    # ------------------------------------------------------------------ small integers: one tensor broadcast
+    def _share_ints(self, values):
+        """rank 0 passes a list of ints; every rank returns it (two int64 broadcasts: count, payload)."""
+        if self.world == 1:
+            return [int(v) for v in values]
+        n = torch.tensor([len(values) if self.rank == 0 else 0], dtype=torch.int64, device=self.comm)
+        dist.broadcast(n, src=0, group=self.group)
+        k = int(n.item())
+        t = torch.tensor(list(values), dtype=torch.int64, device=self.comm) if self.rank == 0 else \
+            torch.empty(k, dtype=torch.int64, device=self.comm)
+        if k:
+            dist.broadcast(t, src=0, group=self.group)
+        return [int(v) for v in t.tolist()]
+
+    def _global_max(self, v):
+        if self.world == 1:
+            return int(v)
+        t = torch.tensor([int(v)], dtype=torch.int64, device=self.comm)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return int(t.item())
+
+    # ------------------------------------------------------------------ point-to-point scatter / gather of row slices
+    def _scatter_rows(self, batch, parts, width, dtype):
+        """rank 0: batch is the padded [B, width] tensor; rank r receives rows parts[r].  Returns this rank's [rows, width]."""
+        a, b = parts[self.rank]
         if self.rank == 0:
-            ops = [dist.P2POp(dist.isend, flats[r].to(self.comm), r, self.group) for r in range(1, self.world) if sizes[r] > 0]
+            ops, keep = [], []
+            for r in range(1, self.world):
+                ra, rb = parts[r]
+                if rb > ra and width > 0:
+                    sl = batch[ra:rb]  # contiguous row slice of the gathered batch: sent as it is
+                    if sl.device != self.comm:
+                        sl = sl.to(self.comm)
+                    keep.append(sl)
+                    ops.append(dist.P2POp(dist.isend, sl, r, self.group))
             if ops:
                 for w in dist.batch_isend_irecv(ops):
                     w.wait()
-            return flats[0]
-        buf = torch.empty(sizes[self.rank], device=self.comm, dtype=dtype)
-        if sizes[self.rank] > 0:
+            return batch[a:b]
+        buf = torch.empty((b - a, width), device=self.comm, dtype=dtype)
+        if b > a and width > 0:
             for w in dist.batch_isend_irecv([dist.P2POp(dist.irecv, buf, 0, self.group)]):
                 w.wait()
-        return buf.to(self.device)
+        return buf if buf.device == self.device else buf.to(self.device)
 
-    def _fan_in(self, flat, sizes, dtype):
-        """every rank contributes a 1-D tensor; rank 0 returns the list of all of them."""
+    def _gather_rows_async(self, mine, parts, width, dtype):
+        """every rank contributes its [rows, width] tensor (contiguous); rank 0 gets a _Pending whose wait() returns the
+        list of per-rank tensors on self.device; other ranks get a _Pending to wait on before `mine` may be freed."""
         if self.rank == 0:
-            bufs = [flat] + [torch.empty(sizes[r], device=self.comm, dtype=dtype) for r in range(1, self.world)]
-            ops = [dist.P2POp(dist.irecv, bufs[r], r, self.group) for r in range(1, self.world) if sizes[r] > 0]
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
-            return [bufs[0]] + [b.to(self.device) for b in bufs[1:]]
-        if sizes[self.rank] > 0:
-            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, flat.to(self.comm), 0, self.group)]):
-                w.wait()
-        return None
-
-    def _share(self, obj):
-        box = [obj]
-        dist.broadcast_object_list(box, src=0, group=self.group)
-        return box[0]
-
-    def encode(self, wav_list=None, overlap_seconds=10):
-        """rank 0 passes the full list; returns {"codes_list": [...]} on rank 0, None elsewhere."""
-        lens = self._share([int(w.shape[-1]) for w in wav_list] if self.rank == 0 else None)
-        parts = partition(lens, self.world)
-        sizes = [sum(lens[a:b]) for a, b in parts]
-        flats = None
-        if self.rank == 0:
-            flats = [torch.cat([w.reshape(-1).to(self.device, torch.float32) for w in wav_list[a:b]]) if b > a
-                     else torch.empty(0, device=self.device) for a, b in parts]
-        mine = self._fan_out(flats, sizes, torch.float32)
+            bufs, ops = [mine], []
+            for r in range(1, self.world):
+                ra, rb = parts[r]
+                t = torch.empty((rb - ra, width), device=self.comm, dtype=dtype)
+                bufs.append(t)
+                if rb > ra and width > 0:
+                    ops.append(dist.P2POp(dist.irecv, t, r, self.group))
+            works = dist.batch_isend_irecv(ops) if ops else []
+            return _Pending(works, bufs)
         a, b = parts[self.rank]
-        local = list(torch.split(mine, lens[a:b])) if b > a else []
+        works = []
+        if b > a and width > 0:
+            src = mine if mine.device == self.comm else mine.to(self.comm)
+            works = dist.batch_isend_irecv([dist.P2POp(dist.isend, src.contiguous(), 0, self.group)])
+            return _Pending(works, [src])
+        return _Pending(works, [])
+
+    # ------------------------------------------------------------------ batch assembly helpers
+    def _pad_batch(self, tensors, lens, dtype, min_len=0):
+        """list of 1-D tensors -> zero-padded [B, max(len, min_len)] on self.device (the codec's own one-kernel gather
+        when it has one)."""
+        if not tensors:
+            return torch.zeros((0, max(int(min_len), 1)), device=self.device, dtype=dtype)
+        stack = getattr(self.codec, "_stack", None)
+        if stack is not None and self.device.type == "cuda":
+            with torch.cuda.device(self.device):
+                return stack([t.reshape(-1) for t in tensors], lens, self.device, dtype, min_len)
+        L = max(max(lens), 1, int(min_len))
+        out = torch.zeros(len(tensors), L, device=self.device, dtype=dtype)
+        for i, t in enumerate(tensors):
+            if lens[i]:
+                out[i, : lens[i]] = t.reshape(-1).to(self.device, dtype)
+        return out
+
+    def _local_encode(self, wav_list, lens, parts, overlap_seconds):
+        L = max(lens) if lens else 0
+        batch = self._pad_batch(wav_list, lens, torch.float32) if self.rank == 0 else None
+        mine = self._scatter_rows(batch, parts, max(L, 1) if lens else 0, torch.float32)
+        a, b = parts[self.rank]
+        local = [mine[i - a, : lens[i]] for i in range(a, b)]
         codes = self.codec.encode(local, overlap_seconds=overlap_seconds, device=self.device)["codes_list"] if local else []
+        return codes
+
+    def _codes_rows(self, codes, clen, a, b, Lc):
+        """local codes list -> padded int32 [(b-a)*G, Lc] rows (row = utterance-major, group-minor)."""
         G = self.codec.num_groups
-        rate = self.codec.encoder_downsample_rate
-        clen = [l // rate for l in lens]
-        csz = [G * sum(clen[a:b]) for a, b in parts]
-        flat = torch.cat([c.to(torch.int32).reshape(-1) for c in codes]) if codes else torch.empty(0, device=self.device, dtype=torch.int32)
-        got = self._fan_in(flat, csz, torch.int32)
-        if self.rank != 0:
-            return None
+        rows = [c[g] if c.dtype == torch.int32 else c[g].to(torch.int32) for c in codes for g in range(G)]
+        return self._pad_batch(rows, [clen[a + k] for k in range(b - a) for _ in range(G)], torch.int32, Lc)
+
+    def _split_codes(self, got, parts, clen):
+        G = self.codec.num_groups
         out = []
         for (a, b), buf in zip(parts, got):
-            off = 0
+            buf = buf if buf.device == self.device else buf.to(self.device)
             for i in range(a, b):
-                out.append(buf[off:off + G * clen[i]].view(G, clen[i]))
-                off += G * clen[i]
-        return {"codes_list": out}
+                out.append(buf[(i - a) * G:(i - a + 1) * G, : clen[i]])
+        return out
+
+    def _split_wavs(self, got, parts, clen):
+        up = self.codec.decoder_upsample_rate
+        out = []
+        for (a, b), buf in zip(parts, got):
+            buf = buf if buf.device == self.device else buf.to(self.device)
+            for i in range(a, b):
+                out.append(buf[i - a, : up * clen[i]])
+        return out
+
+    def _wav_rows(self, wavs, clen, a, b, Lw):
+        return self._pad_batch(list(wavs), [int(w.numel()) for w in wavs], torch.float32, Lw)
+
+    # ------------------------------------------------------------------ public surface
+    def encode(self, wav_list=None, overlap_seconds=10):
+        """rank 0 passes the full list; returns {"codes_list": [...]} on rank 0, None elsewhere."""
+        lens = self._share_ints([int(w.shape[-1]) for w in wav_list] if self.rank == 0 else None)
+        if not lens:
+            return {"codes_list": []} if self.rank == 0 else None
+        parts = partition(lens, self.world)
+        codes = self._local_encode(wav_list, lens, parts, overlap_seconds)
+        rate = self.codec.encoder_downsample_rate
+        clen = [l // rate for l in lens]
+        Lc = max(max(clen), 1)
+        a, b = parts[self.rank]
+        G = self.codec.num_groups
+        cparts = [(pa * G, pb * G) for pa, pb in parts]
+        got = self._gather_rows_async(self._codes_rows(codes, clen, a, b, Lc), cparts, Lc, torch.int32).wait()
+        if self.rank != 0:
+            return None
+        return {"codes_list": self._split_codes(got, parts, clen)}
 
     def decode(self, codes_list=None, overlap_seconds=10):
         """rank 0 passes the full list; returns {"syn_wav_list": [...]} on rank 0, None elsewhere."""
         G = self.codec.num_groups
-        clen = self._share([int(c.shape[-1]) for c in codes_list] if self.rank == 0 else None)
-        t_max = max(clen) if clen else 0
+        clen = self._share_ints([int(c.shape[-1]) for c in codes_list] if self.rank == 0 else None)
+        if not clen:
+            return {"syn_wav_list": []} if self.rank == 0 else None
+        t_max = max(clen)
         parts = partition([max(c, 1) for c in clen], self.world)
-        sizes = [G * sum(clen[a:b]) for a, b in parts]
-        flats = None
-        if self.rank == 0:
-            flats = [torch.cat([c.to(self.device, torch.int32).reshape(-1) for c in codes_list[a:b]]) if b > a
-                     else torch.empty(0, device=self.device, dtype=torch.int32) for a, b in parts]
-        mine = self._fan_out(flats, sizes, torch.int32)
+        Lc = max(t_max, 1)
+        batch = None
+        if self.rank == 0:  # rows = (utterance, group): one padded int32 matrix, shards are row slices of it
+            rows = [c[g].to(torch.int32) for c in codes_list for g in range(G)]
+            batch = self._pad_batch(rows, [n for n in clen for _ in range(G)], torch.int32, Lc)
+        cparts = [(pa * G, pb * G) for pa, pb in parts]
+        mine = self._scatter_rows(batch, cparts, Lc, torch.int32)
         a, b = parts[self.rank]
-        local, off = [], 0
-        for i in range(a, b):
-            local.append(mine[off:off + G * clen[i]].view(G, clen[i]).long())
-            off += G * clen[i]
+        local = [mine[(i - a) * G:(i - a + 1) * G, : clen[i]] for i in range(a, b)]
         wavs = self.codec.decode(local, overlap_seconds=overlap_seconds, device=self.device,
                                  pad_to_length=t_max)["syn_wav_list"] if local else []
         up = self.codec.decoder_upsample_rate
-        wsz = [up * sum(clen[a:b]) for a, b in parts]
-        flat = torch.cat([w.reshape(-1).to(torch.float32) for w in wavs]) if wavs else torch.empty(0, device=self.device)
-        got = self._fan_in(flat, wsz, torch.float32)
+        Lw = max(up * t_max, 1)
+        got = self._gather_rows_async(self._wav_rows(wavs, clen, a, b, Lw), parts, Lw, torch.float32).wait()
         if self.rank != 0:
             return None
-        out = []
-        for (a, b), buf in zip(parts, got):
-            off = 0
-            for i in range(a, b):
-                out.append(buf[off:off + up * clen[i]])
-                off += up * clen[i]
-        return {"syn_wav_list": out}
+        return {"syn_wav_list": self._split_wavs(got, parts, clen)}
+
+    def encode_decode(self, wav_list=None, overlap_seconds=10):
+        """Round trip of one batch (the configs[3] serving step): scatter audio -> encode -> (codes gathered while) decode ->
+        gather waveforms.  The codes never leave their GPU between encode and decode; the one global integer (maximum
+        code length, for the reference's T_max rule) follows from the broadcast lengths.  Rank 0 returns
+        {"codes_list", "syn_wav_list"} equal to codec.decode(codec.encode(all)); other ranks return None."""
+        lens = self._share_ints([int(w.shape[-1]) for w in wav_list] if self.rank == 0 else None)
+        if not lens:
+            return {"codes_list": [], "syn_wav_list": []} if self.rank == 0 else None
+        parts = partition(lens, self.world)
+        codes = self._local_encode(wav_list, lens, parts, overlap_seconds)
+        rate, up, G = self.codec.encoder_downsample_rate, self.codec.decoder_upsample_rate, self.codec.num_groups
+        clen = [l // rate for l in lens]
+        t_max = max(clen)
+        Lc, Lw = max(t_max, 1), max(up * t_max, 1)
+        a, b = parts[self.rank]
+        cparts = [(pa * G, pb * G) for pa, pb in parts]
+        pend_codes = self._gather_rows_async(self._codes_rows(codes, clen, a, b, Lc), cparts, Lc, torch.int32)
+        wavs = self.codec.decode(codes, overlap_seconds=overlap_seconds, device=self.device,
+                                 pad_to_length=t_max)["syn_wav_list"] if codes else []
+        pend_wavs = self._gather_rows_async(self._wav_rows(wavs, clen, a, b, Lw), parts, Lw, torch.float32)
+        got_c = pend_codes.wait()
+        got_w = pend_wavs.wait()
+        if self.rank != 0:
+            return None
+        return {"codes_list": self._split_codes(got_c, parts, clen), "syn_wav_list": self._split_wavs(got_w, parts, clen)}

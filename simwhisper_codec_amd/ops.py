@@ -38,6 +38,10 @@ def _ptr(t):
 def _chk(t, name, dtype=None):
     if not t.is_cuda:
         raise _lib.SwcError(f"{name}: expected a device tensor (the HIP path has no CPU fallback)")
+    if t.device.index != torch._C._cuda_getDevice():
+        raise _lib.SwcError(f"{name}: tensor on cuda:{t.device.index} but cuda:{torch._C._cuda_getDevice()} is current; kernels "
+                            "run on the current device's stream (AudioCodec's entry points set it; direct ops callers "
+                            "use torch.cuda.device)")
     if dtype is not None and t.dtype != dtype:
         raise _lib.SwcError(f"{name}: expected {dtype}, got {t.dtype}")
     return t
@@ -248,3 +252,14 @@ def gather_rows(ptrs_dev, nbytes_dev, n_rows, ld_elems, dtype, device):
     _lib.check(lib.swc_gather_rows(_ptr(ptrs_dev), _ptr(nbytes_dev), _ptr(out), ld_elems * out.element_size(), n_rows,
                                    _stream()), "swc_gather_rows")
     return out
+
+
+def set_saturation_counter(counters):
+    """counters: int32/uint32 device tensor of 2 elements (or None): see swc_set_saturation_counter in include/swc.h.
+    The pointer is per calling thread; the tensor must outlive its use."""
+    lib = _lib.load()
+    if counters is not None:
+        _chk(counters, "saturation counters")
+        if counters.numel() < 2 or counters.element_size() != 4:
+            raise _lib.SwcError("saturation counters: need 2 x 32-bit elements")
+    _lib.check(lib.swc_set_saturation_counter(_ptr(counters)), "swc_set_saturation_counter")

@@ -50,12 +50,18 @@ def _worker(rank, world, port, lens, ret):
         wavs = [torch.randn(n, generator=g) for n in lens] if rank == 0 else None
         enc = dp.encode(wavs)
         dec = dp.decode(enc["codes_list"] if rank == 0 else None)
+        rt = dp.encode_decode(wavs)  # the fused round trip: codes stay on their rank between encode and decode
         if rank == 0:
             want_c = codec.encode(wavs)["codes_list"]
             want_w = codec.decode(want_c)["syn_wav_list"]
             ok = all(torch.equal(a, b) for a, b in zip(enc["codes_list"], want_c)) and len(enc["codes_list"]) == len(lens)
             ok = ok and all(torch.equal(a, b) for a, b in zip(dec["syn_wav_list"], want_w))
+            ok = ok and len(rt["codes_list"]) == len(lens) and len(rt["syn_wav_list"]) == len(lens)
+            ok = ok and all(torch.equal(a, b) for a, b in zip(rt["codes_list"], want_c))
+            ok = ok and all(torch.equal(a, b) for a, b in zip(rt["syn_wav_list"], want_w))
             ret.put(bool(ok))
+        else:
+            assert enc is None and dec is None and rt is None
     finally:
         dist.destroy_process_group()
 

@@ -35,12 +35,15 @@ def _worker(rank, world, port, ret):
             if rank == 0 else None
         enc = dp.encode(wavs)
         dec = dp.decode(enc["codes_list"] if rank == 0 else None)
+        rt = dp.encode_decode(wavs)
         if rank == 0:
             want_c = m.encode(wavs)["codes_list"]
             want_w = m.decode(want_c)["syn_wav_list"]
             ok = len(enc["codes_list"]) == len(lens)
             ok = ok and all(torch.equal(a.long().cpu(), b.long().cpu()) for a, b in zip(enc["codes_list"], want_c))
             ok = ok and all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(dec["syn_wav_list"], want_w))
+            ok = ok and all(torch.equal(a.long().cpu(), b.long().cpu()) for a, b in zip(rt["codes_list"], want_c))
+            ok = ok and all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(rt["syn_wav_list"], want_w))
             ret.put(bool(ok))
     finally:
         dist.destroy_process_group()
@@ -56,4 +59,48 @@ def test_two_ranks_one_gpu_equal_single_process():
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
+
+
+def _worker_nccl(port, ret):
+    """world size 1 on the RCCL backend: init, tensor broadcasts, the scatter / gather code path with device buffers."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from common import PARAMS, state_dict
+    from simwhisper_codec_amd import synth
+    from simwhisper_codec_amd.codec import AudioCodec
+    from simwhisper_codec_amd.dist import DataParallelCodec
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        m = AudioCodec(PARAMS["tiny"](), precision="mixed")
+        m.load_state_dict(state_dict("tiny"), strict=True)
+        m = m.to("cuda:0").eval()
+        dp = DataParallelCodec(m, "cuda:0")
+        lens = [16000 * 3 + 17, 16000 * 2, 5000, 0, 16000 * 4 + 999]
+        wavs = [synth.synth_audio(n, index=310 + i, kind="speech" if i % 2 else "noise").cuda() for i, n in enumerate(lens)]
+        enc = dp.encode(wavs)
+        dec = dp.decode(enc["codes_list"])
+        rt = dp.encode_decode(wavs)
+        t = torch.ones(1, device="cuda:0")
+        dist.all_reduce(t)  # the collective bench.py uses for the MAX over ranks
+        want_c = m.encode(wavs)["codes_list"]
+        want_w = m.decode(want_c)["syn_wav_list"]
+        ok = all(torch.equal(a.long(), b.long()) for a, b in zip(enc["codes_list"], want_c))
+        ok = ok and all(torch.equal(a, b) for a, b in zip(dec["syn_wav_list"], want_w))
+        ok = ok and all(torch.equal(a.long(), b.long()) for a, b in zip(rt["codes_list"], want_c))
+        ok = ok and all(torch.equal(a, b) for a, b in zip(rt["syn_wav_list"], want_w))
+        ret.put(bool(ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_rank_rccl_equals_plain_codec():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    p = ctx.Process(target=_worker_nccl, args=(_free_port(), ret))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
     assert ret.get(timeout=5) is True

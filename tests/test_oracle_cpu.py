@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import GOLD, golden, golden_audio, oracle, state_dict
+from common import GOLD, ROOT, golden, golden_audio, oracle, state_dict
 
 TAGS = ["tiny"] + (["real"] if os.environ.get("SWC_REAL_ORACLE_TESTS", "1") == "1" else [])
 # fp32 on the same CPU/BLAS: the oracle re-orders nothing on purpose, but folded weight-norm
@@ -129,3 +129,19 @@ def test_length_laws():
         mel_len = -(-n // 160)
         assert int(r["codes_lengths"][0]) == -(-(mel_len // 2) // 4)
         assert r["codes"].shape == (8, 1, 375)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/audiocodec"), reason="the reference checkout exists in the build container only")
+def test_golden_generator_reproduces_committed_fixture(tmp_path):
+    """The recipe that pins the oracle must stay runnable: oracle/make_golden.py imports THE REFERENCE (not the repo's
+    own `audiocodec` drop-in package, which once shadowed it) and regenerates tiny_single bit for bit."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "make_golden.py"), "--only", "tiny", "--cases", "single",
+                        "--out", str(tmp_path)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:]
+    new = np.load(tmp_path / "tiny_single.npz", allow_pickle=False)
+    old = np.load(os.path.join(ROOT, "tests", "golden", "tiny_single.npz"), allow_pickle=False)
+    assert set(new.files) == set(old.files)
+    for k in old.files:
+        assert np.array_equal(new[k], old[k]), k

@@ -1,5 +1,8 @@
 #!/bin/bash
-cd $GRAFT_REPO_ROOT
+# tile-order band A/B; needs a tuning build: tools/build_variant.sh tune && SWC_LIB=simwhisper_codec_amd/libswc_tune.so
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$R"
+export SWC_LIB=${SWC_LIB:-$R/simwhisper_codec_amd/libswc_tune.so}
 for rep in 1 2 3; do
   for band in 1 4; do
     echo "== band=$band"

@@ -26,4 +26,4 @@ for _ in range(7):
     for _ in range(5): ops.gemm(A, W, M, N, K, **kw)
     e1.record(); torch.cuda.synchronize(); ts.append(e0.elapsed_time(e1)/5)
 t=statistics.median(ts)
-print(f"{kind} dbg={os.environ.get('SWC_GEMM_DBG','0')} pad={pad} M={M} N={N} K={K} {t*1e3:.1f} us {2.0*M*N*K/t/1e9:.1f} TFLOP/s")
+print(f"{kind} pad={pad} M={M} N={N} K={K} {t*1e3:.1f} us {2.0*M*N*K/t/1e9:.1f} TFLOP/s")
