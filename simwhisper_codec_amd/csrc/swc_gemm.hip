@@ -323,6 +323,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     auto stage_slice = [&](int kt, int stage) {
         const unsigned sa = smem_base + stage * STAGE_BYTES + wave_u * 1024;  // one wave-instruction = 1 KiB of rows
         const unsigned sb = sa + A_BYTES;
+        // Never taken (kc_per_tap >= 1).  The uniform branch makes the LDS-DMA issue block its own scheduling region:
+        // without it hipcc interleaves the fragment reads of the current slice differently with the first MFMAs and
+        // the whole step runs 6.5 % slower (same-box A/B, profiles/r02_ab_sched_region.txt; a sched_barrier(0) in its
+        // place gives a third, also slower, order).
+        if (p.kc_per_tap <= 0) return;
         if constexpr (PLAIN) {
             const long koff = (long)kt * ROW_BYTES;
             const char* ab = a_base + koff;

@@ -6,9 +6,10 @@ Every stage is fed the GOLDEN input of that stage and compared with the golden o
 end-to-end waveform budget.  Error measure: max |hip - ref| / max |ref| over the stage tensor.
 
 Tolerances:
-  fp32   every stage <= 1e-4 (measured 1e-6 .. 8e-6 on MI355X)
-  mixed  encode-side stages (split-f16 x3, f32-class) <= 1e-4; decode-side stages (bf16 operands, f32 accumulate and
-         residual stream) per stage, a factor ~2 above the values measured on MI355X (see TOL below)
+  fp32   every stage <= 1e-4 (measured on MI355X: mel 3.4-4.5e-5 (log10 of small powers), every other stage 0.6-2.2e-6)
+  mixed  encode-side stages (split-f16 x3, f32-class) <= 1e-4 (measured 0.8-1.2e-6); decode-side stages (bf16 operands,
+         f32 accumulate and residual stream) per stage, about 2x the values measured on MI355X:
+         up 4.4-5.2e-3, dec_mel 4.4-6.7e-3, y 0.9-1.4e-2, forward() 1.0-1.6e-2
 """
 import os
 
@@ -26,8 +27,8 @@ TOL = {
     "mel": (1e-4, 1e-4),       # always f32 MFMA (DFT + mel GEMMs)
     "enc": (1e-4, 1e-4),       # conv stem + 12 layers + LN
     "z": (1e-4, 1e-4),         # down-sampler (snake_aa, k7 convs)
-    "up": (1e-4, 2e-2),        # up-sampler: bf16 operands
-    "dec_mel": (1e-4, 3e-2),   # 12 decoder layers + deconvs: bf16 operands
+    "up": (1e-4, 1.2e-2),      # up-sampler: bf16 operands
+    "dec_mel": (1e-4, 1.5e-2), # 12 decoder layers + deconvs: bf16 operands
     "y": (1e-4, 3e-2),         # Vocos + ISTFT: bf16 operands, refit-sigmoid GELU, hardware sine
 }
 
@@ -122,7 +123,10 @@ def test_stage_downsample(tag, name, precision):
         x[:, :Ttok] = enc
         z = m._downsample(m._cast(x.to(DEV), P.edt), B, Tds, P)
         got = z.cpu().numpy()
-    _check("z", tag, name, precision, got, g["st_z"].transpose(0, 2, 1)[:, :Tds])
+    # the path computes ceil(len/4) + 64 frames of the reference's 375: frames within the receptive field (+-59) of that
+    # cut see the boundary, every frame an utterance can use (< ceil(max tokens / 4)) does not
+    Tv = spec.cdiv(Ttok, P.stack)
+    _check("z", tag, name, precision, got[:, :Tv], g["st_z"].transpose(0, 2, 1)[:, :Tv])
 
 
 @pytest.mark.parametrize("tag,name,precision", CASES)
@@ -176,4 +180,4 @@ def test_forward_mixed(tag):
     assert a.shape == g["audio"].shape
     worst = max(_relerr(a[i, :n], g["audio"][i, :n]) for i, n in enumerate(g["audio_lengths"]))
     _report(f"forward_mixed/{tag}", rel_err=worst)
-    assert worst < 5e-2
+    assert worst < 4e-2  # measured 1.0-1.6e-2

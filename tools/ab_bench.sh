@@ -1,0 +1,16 @@
+#!/bin/bash
+# same-box A/B of whole-step throughput for alternative library builds: tools/ab_bench.sh <lib tag> <lib tag> ...
+# (tag "hip" = the product library; others are simwhisper_codec_amd/libswc_<tag>.so, selected with SWC_LIB — the
+# product library is never overwritten)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+cd "$R"
+for rep in 1 2; do
+  for tag in "$@"; do
+    lib=$R/simwhisper_codec_amd/libswc_$tag.so
+    echo "== $tag"
+    SWC_LIB=$lib python bench.py --steps 10 --warmup 3 --cpu-baseline off --no-dist 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); r=d.get('roofline',{})
+print(d['value'], d['ms_per_step'], r.get('kernel'), r.get('achieved'), {k:v['TFLOP/s'] for k,v in r.get('other',{}).items()})"
+  done
+done
