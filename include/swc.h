@@ -150,6 +150,22 @@ int swc_layernorm(const float* x, void* y, const float* w, const float* b, const
                   void* stream);
 
 /*
+ * ConvNeXt back half in one kernel (modules.py:1241-1247, 24x per Vocos call = half of all FLOPs of the path):
+ *     x[M][C] += gamma * ( GELU( y W1^T + b1 ) W2^T + b2 )          pwconv1 -> nn.GELU -> pwconv2 -> gamma -> residual
+ * y: [M][C] bf16 (swc_dwconv7_ln output), x: [M][C] f32 residual stream, updated in place; b1 [I], b2 [C], gamma [C] f32.
+ * The [M][I] intermediate stays on chip (registers -> LDS -> MFMA operand).  Built for C = 512, I % 128 == 0 (the
+ * shipped Vocos: 512 / 4096); other geometries return SWC_E_ARG and the caller runs two swc_gemm calls instead.
+ * `w_stream` is the pair (pwconv1.weight [I][C], pwconv2.weight [C][I]) in bf16, re-ordered ONCE at load by
+ * swc_convnext_pack into the order in which each wave consumes 1 KiB MFMA operand fragments
+ * (swc_convnext_stream_bytes(C, I) bytes, 0 for an unsupported geometry).  bf16 operands, f32 accumulation; GELU is the
+ * refit sigmoid form of the bf16 swc_gemm epilogue (|error| <= 2.7e-4).
+ */
+int64_t swc_convnext_stream_bytes(int32_t C, int32_t I);
+int swc_convnext_pack(const void* w1_bf16, const void* w2_bf16, void* w_stream, int32_t C, int32_t I, void* stream);
+int swc_convnext_mlp(const void* y, const void* w_stream, const float* b1, const float* b2, const float* gamma,
+                     float* x, int32_t M, int32_t C, int32_t I, void* stream);
+
+/*
  * ConvNeXt front half: depthwise Conv1d(k=7, pad=3, groups=C) + LayerNorm(eps)
  * (modules.py:1233-1239).  x: [B][T][C] f32, w: [7][C], y: [B][T][C] (y_dtype).
  */

@@ -64,8 +64,11 @@ SIGNATURES = {
     "swc_cast_fp8": [_P, _I, _P, _L, _F, _P],
     "swc_gather_rows": [_P, _P, _P, _L, _I, _P],
     "swc_set_saturation_counter": [_P],
+    "swc_convnext_pack": [_P, _P, _P, _I, _I, _P],
+    "swc_convnext_mlp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
 }
-PLAIN = {"swc_version": ([], C.c_int), "swc_last_error": ([], C.c_char_p), "swc_device_count": ([], C.c_int)}
+PLAIN = {"swc_version": ([], C.c_int), "swc_last_error": ([], C.c_char_p), "swc_device_count": ([], C.c_int),
+         "swc_convnext_stream_bytes": ([_I, _I], C.c_int64)}
 
 _lib = None
 

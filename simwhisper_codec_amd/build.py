@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libswc_hip.so")
-SOURCES = ["swc_api.hip", "swc_gemm.hip", "swc_attention.hip", "swc_attention16.hip", "swc_pointwise.hip"]
+SOURCES = ["swc_api.hip", "swc_gemm.hip", "swc_attention.hip", "swc_attention16.hip", "swc_pointwise.hip", "swc_convnext.hip"]
 ARCH = "gfx950"
 # per-file flags.  -fno-slp-vectorize: hipcc otherwise packs adjacent f32 mul/add/fma into v_pk_*_f32, which issue at
 # half rate on gfx950 and cost extra v_mov shuffles — slower beside MFMAs (softmax, epilogues)

@@ -376,6 +376,8 @@ class AudioCodec(nn.Module):
         P.emw, P.emb = W(conv_w(sd[p + "embed.weight"]), ddt), V(sd[p + "embed.bias"])
         P.vnorm = (V(sd[p + "norm.weight"]), V(sd[p + "norm.bias"]))
         P.blocks = []
+        # the fused MLP kernel (swc_convnext_mlp) exists for the shipped geometry with bf16 operands
+        P.fused_mlp = ddt == torch.bfloat16 and ops.convnext_supported(P.vdim, P.vint)
         for i in range(v["num_layers"]):
             b_ = f"{p}convnext.{i}."
             P.blocks.append(dict(
@@ -383,6 +385,9 @@ class AudioCodec(nn.Module):
                 ln=(V(sd[b_ + "norm.weight"]), V(sd[b_ + "norm.bias"])),
                 w1=W(sd[b_ + "pwconv1.weight"], ddt), b1=V(sd[b_ + "pwconv1.bias"]),
                 w2=W(sd[b_ + "pwconv2.weight"], ddt), b2=V(sd[b_ + "pwconv2.bias"]), g=V(sd[b_ + "gamma"])))
+            if P.fused_mlp:
+                blk = P.blocks[-1]
+                blk["ws"] = ops.convnext_pack(blk["w1"].w, blk["w2"].w)
         P.vfin = (V(sd[p + "final_layer_norm.weight"]), V(sd[p + "final_layer_norm.bias"]))
         P.hw, P.hb = W(sd["vocos.head.out.weight"], ddt), V(sd["vocos.head.out.bias"])
         win = sd["vocos.head.istft.window"].float()
@@ -558,8 +563,14 @@ class AudioCodec(nn.Module):
         dt, C, M = P.ddt, P.vdim, B * Tv
         x = self._mm(mel, P.emw, M, C, P.vin, lda=P.vin, ldw=7 * P.vin, bias=P.emb, taps=7, pad=3, t_in=Tv, t_out=Tv)
         x = ops.layernorm(x, P.vnorm[0], P.vnorm[1], 1e-6, B=B, t_in=Tv, C_=C)
+        # one fused kernel per block when the grid fills the chip (128-frame tiles, one per CU); small batches keep the
+        # two-GEMM form, whose 128 x 128 tiles spread over more CUs
+        fused = P.fused_mlp and M >= self.fused_mlp_min_rows
         for blk in P.blocks:
             y = ops.dwconv7_ln(x, blk["dw"], blk["db"], blk["ln"][0], blk["ln"][1], 1e-6, B=B, T=Tv, C_=C, out_dtype=dt)
+            if fused:
+                ops.convnext_mlp(y, blk["ws"], blk["b1"], blk["b2"], blk["g"], x, M=M, C_=C, I=P.vint)
+                continue
             y = self._mm(y, blk["w1"], M, P.vint, C, lda=C, bias=blk["b1"], act=ops.ACT_GELU, out_dtype=dt)
             self._mm(y, blk["w2"], M, C, P.vint, lda=P.vint, bias=blk["b2"], gamma=blk["g"], residual=x, out=x)
         hn = ops.layernorm(x, P.vfin[0], P.vfin[1], 1e-6, B=B, t_in=Tv, C_=C, out_dtype=dt)
@@ -657,6 +668,7 @@ class AudioCodec(nn.Module):
     # long-form scheduling: windows of one call are independent rows, so several 30 s windows are batched into
     # one tokenize / detokenize call (the reference loops them serially, model.py:275,340)
     max_rows_per_call = 64
+    fused_mlp_min_rows = 128 * 160  # Vocos frames from which the fused ConvNeXt MLP kernel is used (>= 160 of 256 CUs busy)
     trim_vocos = True  # decode(): run Vocos only on the kept frames (+ halo) of each window; bit-identical output
 
     def _stack(self, tensors, lens, dev, dtype, min_len=0):

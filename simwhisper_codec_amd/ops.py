@@ -263,3 +263,37 @@ def set_saturation_counter(counters):
         if counters.numel() < 2 or counters.element_size() != 4:
             raise _lib.SwcError("saturation counters: need 2 x 32-bit elements")
     _lib.check(lib.swc_set_saturation_counter(_ptr(counters)), "swc_set_saturation_counter")
+
+
+def convnext_supported(C_, I):
+    return _lib.load().swc_convnext_stream_bytes(C_, I) > 0
+
+
+def convnext_pack(w1, w2):
+    """pwconv1.weight [I, C] and pwconv2.weight [C, I] (bf16, device) -> the packed operand stream of swc_convnext_mlp."""
+    lib = _lib.load()
+    _chk(w1, "convnext_pack w1", torch.bfloat16); _chk(w2, "convnext_pack w2", torch.bfloat16)
+    I, C_ = w1.shape
+    if tuple(w2.shape) != (C_, I):
+        raise _lib.SwcError(f"convnext_pack: w2 is {tuple(w2.shape)}, expected {(C_, I)}")
+    n = lib.swc_convnext_stream_bytes(C_, I)
+    if n <= 0:
+        raise _lib.SwcError(f"convnext_pack: unsupported geometry C={C_} I={I}")
+    out = torch.empty(n, dtype=torch.uint8, device=w1.device)
+    _lib.check(lib.swc_convnext_pack(_ptr(w1.contiguous()), _ptr(w2.contiguous()), _ptr(out), C_, I, _stream()),
+               "swc_convnext_pack")
+    return out
+
+
+def convnext_mlp(y, w_stream, b1, b2, gamma, x, *, M, C_, I):
+    """x[M, C] += gamma * (GELU(y W1^T + b1) W2^T + b2) in one kernel; y bf16 [M, C], x f32 [M, C] (in place)."""
+    lib = _lib.load()
+    _chk(y, "convnext_mlp y", torch.bfloat16); _chk(x, "convnext_mlp x", torch.float32)
+    prof = PROFILER
+    if prof is not None:
+        prof.begin("convnext_bf16", 4.0 * M * C_ * I)
+    _lib.check(lib.swc_convnext_mlp(_ptr(y), _ptr(w_stream), _ptr(b1), _ptr(b2), _ptr(gamma), _ptr(x), M, C_, I, _stream()),
+               "swc_convnext_mlp")
+    if prof is not None:
+        prof.end()
+    return x

@@ -650,3 +650,36 @@ def test_gather_rows():
         for i, r in enumerate(rows):
             want[i, : ln[i]] = r.cpu()
         assert torch.equal(out.cpu(), want)
+
+
+@pytest.mark.parametrize("M,I", [(300, 256), (128, 128), (1000, 4096), (77, 512)])
+def test_convnext_mlp_fused(M, I):
+    """swc_convnext_mlp (one kernel, intermediate on chip) vs (a) an f64 evaluation of modules.py:1241-1247 on the same
+    bf16 operands and (b) the two-GEMM path it replaces.  M covers partial tiles, I one to 32 hidden slices."""
+    ops = _ops()
+    C = 512
+    g = torch.Generator().manual_seed(M * 7 + I)
+    y = (torch.randn(M, C, generator=g)).to(torch.bfloat16)
+    w1 = (torch.randn(I, C, generator=g) * C ** -0.5).to(torch.bfloat16)
+    w2 = (torch.randn(C, I, generator=g) * I ** -0.5).to(torch.bfloat16)
+    b1, b2 = torch.randn(I, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    gam = torch.randn(C, generator=g)
+    x0 = torch.randn(M, C, generator=g)
+    h = F.gelu(y.double() @ w1.double().T + b1.double())
+    ref = x0.double() + gam.double() * (h @ w2.double().T + b2.double())
+    yd, w1d, w2d = y.to(DEV), w1.to(DEV), w2.to(DEV)
+    ws = ops.convnext_pack(w1d, w2d)
+    x = x0.to(DEV).clone()
+    ops.convnext_mlp(yd, ws, b1.to(DEV), b2.to(DEV), gam.to(DEV), x, M=M, C_=C, I=I)
+    # the two-GEMM path
+    hh = ops.gemm(yd, w1d, M, I, C, bias=b1.to(DEV), act=ops.ACT_GELU, out_dtype=torch.bfloat16)
+    x2 = x0.to(DEV).clone()
+    ops.gemm(hh, w2d, M, C, I, bias=b2.to(DEV), gamma=gam.to(DEV), residual=x2, out=x2)
+    scale = float((ref - x0.double()).abs().max())
+    e_ref = float((x.cpu().double() - ref).abs().max()) / scale
+    e_two = float((x.cpu().double() - x2.cpu().double()).abs().max()) / scale
+    e_two_ref = float((x2.cpu().double() - ref).abs().max()) / scale
+    assert torch.isfinite(x).all()
+    assert e_ref < 1e-2, (e_ref, e_two_ref)        # bf16 intermediate: same class as the two-GEMM path
+    assert e_ref < 2.0 * e_two_ref + 1e-4, (e_ref, e_two_ref)
+    assert e_two < 5e-3, e_two
