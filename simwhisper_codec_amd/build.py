@@ -16,7 +16,7 @@ SOURCES = ["swc_api.hip", "swc_gemm.hip", "swc_attention.hip", "swc_attention16.
 ARCH = "gfx950"
 # per-file flags.  -fno-slp-vectorize: hipcc otherwise packs adjacent f32 mul/add/fma into v_pk_*_f32, which issue at
 # half rate on gfx950 and cost extra v_mov shuffles — slower beside MFMAs (softmax, epilogues)
-EXTRA_FLAGS = {"swc_attention16.hip": ["-fno-slp-vectorize"]}  # measured slower for swc_gemm.hip (-10 %)
+EXTRA_FLAGS = {"swc_attention16.hip": ["-fno-slp-vectorize"], "swc_convnext.hip": ["-fno-slp-vectorize"]}  # measured slower for swc_gemm.hip (-10 %)
 
 
 def _hipcc():

@@ -26,6 +26,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));  // one MFMA operand fragment (8 bf16) as a native vector: asm "v" operand
 
 constexpr int CX_C = 512;        // channels (K of GEMM1, N of GEMM2)
 constexpr int CX_BM = 128;       // frames per workgroup
@@ -47,16 +48,34 @@ __device__ __forceinline__ void cx_glds16(const void* gsrc, unsigned lds_addr) {
 }
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+    unsigned r;  // one v_cvt_pk_bf16_f32 for the pair (RNE; hipcc has no builtin and emits two conversions + shift + or)
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 
-__device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, f32x16 c) {
+// GEMM1's MFMAs in VGPR form.  The 256 accumulators of GEMM2 fill the AGPR half of the register file; left to hipcc, the
+// 64 accumulators of GEMM1 are also given AGPR-form MFMAs and the two sets are shuffled between the halves with ~1500
+// v_accvgpr_read/write/mov per slice (6 k issue cycles beside 8 k MFMA cycles).  Written as asm with "v" operands these
+// four MFMAs keep their accumulators in VGPRs, where the GELU reads them directly.  One statement per k-step: the
+// leading s_nop 1 covers a VALU copy of an operand hipcc may have placed right in front (it pads nothing inside asm).
+__device__ __forceinline__ void mfma32x4_vgpr(const u32x4& a, const u32x4& b0, const u32x4& b1, const u32x4& b2, const u32x4& b3,
+                                              f32x16& c0, f32x16& c1, f32x16& c2, f32x16& c3) {
+    asm("s_nop 1\n\t"
+        "v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\t"
+        "v_mfma_f32_32x32x16_bf16 %1, %4, %6, %1\n\t"
+        "v_mfma_f32_32x32x16_bf16 %2, %4, %7, %2\n\t"
+        "v_mfma_f32_32x32x16_bf16 %3, %4, %8, %3"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
+
+__device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b),
                                                    c, 0, 0, 0);
 }
 
 // wstream: per wave w (4 of them) NS * 64 + CX_PF fragments of 1 KiB in the order of consumption (swc_convnext_pack)
-__global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __restrict__ y, const uint4* __restrict__ wstream,
+__global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __restrict__ y, const u32x4* __restrict__ wstream,
                                                              const float* __restrict__ b1, const float* __restrict__ b2,
                                                              const float* __restrict__ gamma, float* __restrict__ x, int M,
                                                              int NS) {
@@ -83,16 +102,21 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    const uint4* ylds = reinterpret_cast<const uint4*>(smem) + lane;
-    uint4* hlds = reinterpret_cast<uint4*>(smem + CX_Y_BYTES) + lane;
+    const u32x4* ylds = reinterpret_cast<const u32x4*>(smem) + lane;
+    u32x4* hlds = reinterpret_cast<u32x4*>(smem + CX_Y_BYTES) + lane;
 
     // ---- weight stream of this wave
+    // address = wave-uniform byte pointer (SGPR pair, advanced once per phase) + one 32-bit lane offset + immediate:
+    // per-fragment 64-bit VGPR addresses cost 28 registers and a spill in the slice loop
     const long per_wave = (long)NS * 64 + CX_PF;  // fragments
-    const uint4* wp = wstream + ((long)w * per_wave) * 64 + lane;
-    uint4 ring[CX_PF];
+    const char* wbase = reinterpret_cast<const char*>(wstream) + (long)w * per_wave * 1024;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    auto wfrag = [&](int i) -> u32x4 {  // fragment i of the current phase (i may run CX_PF past its end)
+        return *reinterpret_cast<const u32x4*>(wbase + (long)i * 1024 + lane_off);
+    };
+    u32x4 ring[CX_PF];
 #pragma unroll
-    for (int i = 0; i < CX_PF; ++i) ring[i] = wp[(long)i * 64];
-    long fi = 0;  // index of the next fragment to consume; fragment fi + CX_PF is fetched when fi is consumed
+    for (int i = 0; i < CX_PF; ++i) ring[i] = wfrag(i);
 
     f32x16 acc2[4][4];  // [n block of this wave][frame block]
 #pragma unroll
@@ -102,72 +126,102 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.f;
     f32x16 acc1[4];  // [frame block]: H^T tile of this wave's 32 hidden rows
-    float4 bias[4];  // b1 of those rows: bias[g][e] belongs to accumulator register 4 g + e
 
+    // Every k-step is its own scheduling region (sched_barrier at its end): the step issues the refill of the ring slot it
+    // consumes and the LDS reads of the NEXT step's B fragments, then its MFMAs.  Left to itself hipcc sinks the ring
+    // loads to the end of the unrolled trip (issue -> use distance of two MFMAs instead of eight steps) and reads each B
+    // fragment right in front of its MFMA (LDS latency exposed on every pair, one wave per SIMD has nobody to hide it).
+    auto y_frags = [&](int s, u32x4 (&dst)[4]) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dst[b] = ylds[(s * 4 + b) * 64];
+    };
+    auto h_frags = [&](int q, u32x4 (&dst)[4]) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dst[b] = hlds[(q * 4 + b) * 64];
+    };
+    // b1 of this wave's 32 hidden rows, one slice ahead: register r = 4 g + e of a lane in half lh belongs to row
+    // 8 g + 4 lh + e.  Loaded a whole slice before its use, so waiting for it never drains the younger ring loads
+    float4 bias_nx[4];
+    auto load_bias = [&](int j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            bias_nx[g] = *reinterpret_cast<const float4*>(b1 + (long)j * CX_SL + 32 * w + 8 * g + 4 * lh);
+    };
+    load_bias(0);
     auto gemm1 = [&](int j) {
+        // accumulators start at the bias
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc1[b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc1[b][r] = reinterpret_cast<const float*>(&bias_nx[r >> 2])[r & 3];
+        load_bias(j + 1 < NS ? j + 1 : 0);
+        u32x4 yA[4], yB[4];
+        y_frags(0, yA);
+        // fully unrolled: in a rolled loop the ring is loop-carried and hipcc copies all eight slots at the loop head,
+        // which waits for (nearly) every load in flight and cuts the prefetch distance to one or two steps
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            bias[g] = *reinterpret_cast<const float4*>(b1 + (long)j * CX_SL + 32 * w + 8 * g + 4 * lh);
-#pragma nounroll
-        for (int s0 = 0; s0 < 32; s0 += CX_PF) {  // the ring turns once per trip: static register indices inside
+        for (int s0 = 0; s0 < 32; s0 += CX_PF) {
 #pragma unroll
-            for (int u = 0; u < CX_PF; ++u) {
-                const uint4 a = ring[u];
-                ring[u] = wp[(fi + s0 + u + CX_PF) * 64];
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const uint4 yb = ylds[((s0 + u) * 4 + b) * 64];
-                    acc1[b] = mfma32(a, yb, acc1[b]);
+            for (int u = 0; u < CX_PF; u += 2) {
+                {
+                    y_frags(s0 + u + 1, yB);
+                    mfma32x4_vgpr(ring[u], yA[0], yA[1], yA[2], yA[3], acc1[0], acc1[1], acc1[2], acc1[3]);
+                    ring[u] = wfrag(s0 + u + CX_PF);  // refill the slot just consumed (no copy of the operand)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                {
+                    y_frags((s0 + u + 2) & 31, yA);  // the last step re-reads step 0 (harmless)
+                    mfma32x4_vgpr(ring[u + 1], yB[0], yB[1], yB[2], yB[3], acc1[0], acc1[1], acc1[2], acc1[3]);
+                    ring[u + 1] = wfrag(s0 + u + 1 + CX_PF);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
-        fi += 32;
+        // MFMA results in VGPRs -> VALU readers: the wait states hipcc would insert for its own MFMAs (asm is opaque to it)
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc1[0]), "+v"(acc1[1]), "+v"(acc1[2]), "+v"(acc1[3]));
+        wbase += 32 * 1024;
     };
-    // GELU(acc + bias) of accumulator registers 8 t .. 8 t + 7 of frame block b -> one packed B fragment (k-step t)
-    auto gelu_frag = [&](int b, int t) -> uint4 {
+    // GELU of accumulator registers 8 t .. 8 t + 7 of frame block b -> one packed B fragment (k-step t), kept IN PLACE:
+    // its four dwords replace registers 4 t .. 4 t + 3 of the same tile (already consumed), so the packed copy of the
+    // slice costs no registers of its own
+    auto gelu_frag = [&](int b, int t) {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int r = 8 * t + e;
-            const float bb = reinterpret_cast<const float*>(&bias[r >> 2])[r & 3];
-            v[e] = gelu_fast(acc1[b][r] + bb);
-        }
-        uint4 u;
-        u.x = pack_bf16x2(v[0], v[1]); u.y = pack_bf16x2(v[2], v[3]);
-        u.z = pack_bf16x2(v[4], v[5]); u.w = pack_bf16x2(v[6], v[7]);
-        return u;
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fast(acc1[b][8 * t + e]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc1[b][4 * t + i] = __uint_as_float(pack_bf16x2(v[2 * i], v[2 * i + 1]));
     };
-    uint4 hp[4][2];  // packed GELU outputs of this wave: [frame block][k-step]
     auto store_h = [&]() {
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int t = 0; t < 2; ++t) hlds[((2 * w + t) * 4 + b) * 64] = hp[b][t];
+            for (int t = 0; t < 2; ++t)
+                hlds[((2 * w + t) * 4 + b) * 64] =
+                    (u32x4){__float_as_uint(acc1[b][4 * t]), __float_as_uint(acc1[b][4 * t + 1]),
+                            __float_as_uint(acc1[b][4 * t + 2]), __float_as_uint(acc1[b][4 * t + 3])};
     };
     // GEMM2 over the slice whose H^T is in LDS; `with_gelu`: the GELU of the NEXT slice (acc1) rides along, one packed
-    // fragment per k-step
+    // fragment per k-step, in the same scheduling region as that step's 16 MFMAs
     auto gemm2 = [&](auto with_gelu) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            uint4 a[4], hb[4];
+        u32x4 hA[4], hB[4];
+        h_frags(0, hA);
+        auto step = [&](int q, u32x4 (&cur)[4], u32x4 (&nxt)[4]) {
+            if (q + 1 < 8) h_frags(q + 1, nxt);
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                a[n] = ring[(q * 4 + n) % CX_PF];
-                ring[(q * 4 + n) % CX_PF] = wp[(fi + q * 4 + n + CX_PF) * 64];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc2[n][b] = mfma32(ring[(q * 4 + n) % CX_PF], cur[b], acc2[n][b]);
+                ring[(q * 4 + n) % CX_PF] = wfrag(q * 4 + n + CX_PF);
             }
+            if constexpr (decltype(with_gelu)::value) gelu_frag(q >> 1, q & 1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
 #pragma unroll
-            for (int b = 0; b < 4; ++b) hb[b] = hlds[(q * 4 + b) * 64];
-#pragma unroll
-            for (int n = 0; n < 4; ++n)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc2[n][b] = mfma32(a[n], hb[b], acc2[n][b]);
-            if constexpr (decltype(with_gelu)::value) hp[q >> 1][q & 1] = gelu_frag(q >> 1, q & 1);
+        for (int q = 0; q < 8; q += 2) {
+            step(q, hA, hB);
+            step(q + 1, hB, hA);
         }
-        fi += 32;
+        wbase += 32 * 1024;
     };
 
     // ---- pipeline over the hidden slices
@@ -175,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) hp[b][t] = gelu_frag(b, t);
+        for (int t = 0; t < 2; ++t) gelu_frag(b, t);
     store_h();
     __syncthreads();
     for (int j = 1; j < NS; ++j) {
@@ -298,7 +352,7 @@ extern "C" int swc_convnext_mlp(const void* y, const void* w_stream, const float
     auto kern = convnext_mlp_kernel;
     SWC_ENABLE_LDS(kern, CX_LDS, "swc_convnext_mlp");
     const unsigned grid = (unsigned)((M + CX_BM - 1) / CX_BM);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CX_LDS, (hipStream_t)stream, (const bf16_t*)y, (const uint4*)w_stream,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CX_LDS, (hipStream_t)stream, (const bf16_t*)y, (const u32x4*)w_stream,
                        b1, b2, gamma, x, M, I / CX_SL);
     SWC_CHECK_LAUNCH("swc_convnext_mlp");
     return SWC_OK;
