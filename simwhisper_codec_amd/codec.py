@@ -694,17 +694,33 @@ class AudioCodec(nn.Module):
     def encode(self, wav_list, overlap_seconds=10, device=torch.device("cuda")):
         """model.py:244-308: 30 s windows every (30 - overlap) s, keep the first 250 codes of each window,
         concatenate, trim to len // 1280.  Returns {"codes_list": [IntTensor(G, T_i)]}."""
-        sr, rate = self.input_sample_rate, self.encoder_downsample_rate
-        chunk = int(self.max_audio_seconds * sr)
-        dur = int((self.max_audio_seconds - overlap_seconds) * sr)
-        keep = dur // rate
         B = len(wav_list)
         if B == 0:
             return {"codes_list": []}
         n = [int(w.shape[-1]) if w.dim() else 0 for w in wav_list]
-        L = max(n)
         dev = self._resolve_device(device)
         wav = self._stack(wav_list, n, dev, torch.float32)
+        allc = self._encode_padded(wav, n, overlap_seconds)
+        rate = self.encoder_downsample_rate
+        if allc is None:
+            return {"codes_list": [torch.zeros(self.num_groups, 0, device=dev, dtype=torch.long) for _ in range(B)]}
+        return {"codes_list": [allc[:, i, : n[i] // rate] for i in range(B)]}
+
+    @_on_model_device
+    @torch.inference_mode()
+    def encode_padded(self, wav, n, overlap_seconds=10):
+        """The batch form of encode() (the data-parallel wrapper's fast path): wav [B, L] f32 on the model's GPU, zero
+        padded, n = list of valid lengths.  Returns codes (G, B, Lc) int32, zero beyond n_i // 1280 (Lc >= max of them),
+        or None when no utterance reaches one code frame."""
+        return self._encode_padded(wav, [int(v) for v in n], overlap_seconds)
+
+    def _encode_padded(self, wav, n, overlap_seconds):
+        sr, rate = self.input_sample_rate, self.encoder_downsample_rate
+        chunk = int(self.max_audio_seconds * sr)
+        dur = int((self.max_audio_seconds - overlap_seconds) * sr)
+        keep = dur // rate
+        B, dev = wav.shape[0], wav.device
+        L = max(n)
         wins = []
         for c in range(spec.cdiv(L, dur) if L else 0):
             s0, e0 = c * dur, min(c * dur + chunk, L)
@@ -712,7 +728,7 @@ class AudioCodec(nn.Module):
             if max(cl) > 0:
                 wins.append((s0, e0, cl))
         if not wins:
-            return {"codes_list": [torch.zeros(self.num_groups, 0, device=dev, dtype=torch.long) for _ in range(B)]}
+            return None
         parts = []
         per_call = max(1, self.max_rows_per_call // B)
         for w0 in range(0, len(wins), per_call):
@@ -731,8 +747,7 @@ class AudioCodec(nn.Module):
             # keeping the first `keep` frames of every window reproduces model.py:291-297 without the copy loop
             for k in range(len(grp)):
                 parts.append(r["codes"][:, k * B:(k + 1) * B, :keep])
-        allc = torch.cat(parts, dim=-1) if len(parts) > 1 else parts[0]
-        return {"codes_list": [allc[:, i, : n[i] // rate] for i in range(B)]}
+        return torch.cat(parts, dim=-1) if len(parts) > 1 else parts[0]
 
     @_on_model_device
     @torch.inference_mode()
@@ -742,10 +757,6 @@ class AudioCodec(nn.Module):
         pad_to_length (extension): pad the batch to at least this many code frames — a shard of a larger
         batch passes the global maximum so that its results equal the un-sharded call (the reference's
         up-sampler / Vocos are not masked, so outputs depend on the padded batch length)."""
-        sr, rate = self.input_sample_rate, self.encoder_downsample_rate
-        win = int(self.max_audio_seconds * sr // rate)
-        step = int((self.max_audio_seconds - overlap_seconds) * sr // rate)
-        keep = step * self.decoder_upsample_rate
         B = len(codes_list)
         if B == 0:
             return {"syn_wav_list": []}
@@ -772,11 +783,31 @@ class AudioCodec(nn.Module):
             codes = torch.zeros(self.num_groups, B, L, device=dev, dtype=torch.long)
             for i, c in enumerate(codes_list):
                 codes[:, i, : n[i]] = c.to(dev)
+        wav = self._decode_padded(codes, n, overlap_seconds)
+        return {"syn_wav_list": [wav[i, : n[i] * self.decoder_upsample_rate] for i in range(B)]}
+
+    @_on_model_device
+    @torch.inference_mode()
+    def decode_padded(self, codes, n, overlap_seconds=10, pad_to_length=None):
+        """The batch form of decode(): codes (G, B, L) integer on the model's GPU, zero padded, n = valid code counts;
+        pad_to_length as in decode().  Returns wav [B, max(L, pad_to_length) * 1280] f32 (row i valid up to n_i * 1280)."""
+        L = max(int(codes.shape[-1]), int(pad_to_length or 0))
+        codes = codes.to(torch.long)
+        if L > codes.shape[-1]:
+            codes = torch.nn.functional.pad(codes, (0, L - codes.shape[-1]))
+        return self._decode_padded(codes, [int(v) for v in n], overlap_seconds)
+
+    def _decode_padded(self, codes, n, overlap_seconds):
+        sr, rate = self.input_sample_rate, self.encoder_downsample_rate
+        win = int(self.max_audio_seconds * sr // rate)
+        step = int((self.max_audio_seconds - overlap_seconds) * sr // rate)
+        keep = step * self.decoder_upsample_rate
+        B, L = codes.shape[1], codes.shape[2]
         wins = []
         for c in range(spec.cdiv(L, step)):
             s0, e0 = c * step, min(c * step + win, L)
             cl = [min(max(v - s0, 0), e0 - s0) for v in n]
-            if max(cl) > 0:
+            if max(cl) > 0 or c == 0:
                 wins.append((c, s0, e0, cl))
         # windows of EQUAL padded length are independent rows of one call; a shorter (last) window must keep its
         # own padded length, because the un-masked up-sampler / Vocos see that boundary
@@ -799,8 +830,7 @@ class AudioCodec(nn.Module):
                 for k, wdw in enumerate(grp):
                     parts[wdw[0]] = y[k * B:(k + 1) * B, 0, :keep]
         order = sorted(parts)
-        wav = torch.cat([parts[c] for c in order], dim=-1) if len(order) > 1 else parts[order[0]]
-        return {"syn_wav_list": [wav[i, : n[i] * self.decoder_upsample_rate] for i in range(B)]}
+        return torch.cat([parts[c] for c in order], dim=-1) if len(order) > 1 else parts[order[0]]
 
     @_on_model_device
     @torch.inference_mode()

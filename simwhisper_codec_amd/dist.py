@@ -148,19 +148,50 @@ class DataParallelCodec:
         return out
 
     def _local_encode(self, wav_list, lens, parts, overlap_seconds):
+        """scatter + this rank's encode.  Returns its codes as a padded (G, rows, Lc') tensor (codecs with the batch entry
+        points encode_padded / decode_padded: no per-utterance tensors at all) or as a list of (G, T_i) tensors."""
         L = max(lens) if lens else 0
         batch = self._pad_batch(wav_list, lens, torch.float32) if self.rank == 0 else None
         mine = self._scatter_rows(batch, parts, max(L, 1) if lens else 0, torch.float32)
         a, b = parts[self.rank]
+        if b == a:
+            return []
+        if hasattr(self.codec, "encode_padded"):
+            return self.codec.encode_padded(mine, lens[a:b], overlap_seconds=overlap_seconds)  # tensor or None
         local = [mine[i - a, : lens[i]] for i in range(a, b)]
-        codes = self.codec.encode(local, overlap_seconds=overlap_seconds, device=self.device)["codes_list"] if local else []
-        return codes
+        return self.codec.encode(local, overlap_seconds=overlap_seconds, device=self.device)["codes_list"]
 
     def _codes_rows(self, codes, clen, a, b, Lc):
-        """local codes list -> padded int32 [(b-a)*G, Lc] rows (row = utterance-major, group-minor)."""
+        """local codes (padded tensor, None or list) -> padded int32 [(b-a)*G, Lc] rows (utterance-major, group-minor)."""
         G = self.codec.num_groups
+        if codes is None or torch.is_tensor(codes):
+            rows = torch.zeros(((b - a) * G, Lc), device=self.device, dtype=torch.int32)
+            if codes is not None:
+                wdt = min(Lc, codes.shape[2])
+                rows.view(b - a, G, Lc)[:, :, :wdt] = codes[:, :, :wdt].permute(1, 0, 2)
+            return rows
         rows = [c[g] if c.dtype == torch.int32 else c[g].to(torch.int32) for c in codes for g in range(G)]
         return self._pad_batch(rows, [clen[a + k] for k in range(b - a) for _ in range(G)], torch.int32, Lc)
+
+    def _local_decode(self, codes, clen, a, b, t_max, overlap_seconds, Lw):
+        """this rank's decode of `codes` (padded (G, rows, L) tensor, None or list) -> f32 rows [(b-a), Lw] for the gather."""
+        if b == a:
+            return torch.zeros((0, Lw), device=self.device, dtype=torch.float32)
+        if hasattr(self.codec, "decode_padded") and (codes is None or torch.is_tensor(codes)):
+            if codes is None:
+                codes = torch.zeros((self.codec.num_groups, b - a, 1), device=self.device, dtype=torch.int32)
+            # encode_padded returns whole windows (zero codes beyond each length): the batch the reference would decode
+            # is padded to the longest utterance of the WHOLE batch and no further (its results depend on that length)
+            codes = codes[:, :, : max(t_max, 1)]
+            wav = self.codec.decode_padded(codes, clen[a:b], overlap_seconds=overlap_seconds, pad_to_length=t_max)
+            if wav.shape[1] == Lw and wav.is_contiguous():
+                return wav
+            rows = torch.zeros((b - a, Lw), device=self.device, dtype=torch.float32)
+            rows[:, : min(Lw, wav.shape[1])] = wav[:, :Lw]
+            return rows
+        wavs = self.codec.decode(list(codes), overlap_seconds=overlap_seconds, device=self.device,
+                                 pad_to_length=t_max)["syn_wav_list"] if codes else []
+        return self._pad_batch(list(wavs), [int(w.numel()) for w in wavs], torch.float32, Lw)
 
     def _split_codes(self, got, parts, clen):
         G = self.codec.num_groups
@@ -179,9 +210,6 @@ class DataParallelCodec:
             for i in range(a, b):
                 out.append(buf[i - a, : up * clen[i]])
         return out
-
-    def _wav_rows(self, wavs, clen, a, b, Lw):
-        return self._pad_batch(list(wavs), [int(w.numel()) for w in wavs], torch.float32, Lw)
 
     # ------------------------------------------------------------------ public surface
     def encode(self, wav_list=None, overlap_seconds=10):
@@ -218,12 +246,14 @@ class DataParallelCodec:
         cparts = [(pa * G, pb * G) for pa, pb in parts]
         mine = self._scatter_rows(batch, cparts, Lc, torch.int32)
         a, b = parts[self.rank]
-        local = [mine[(i - a) * G:(i - a + 1) * G, : clen[i]] for i in range(a, b)]
-        wavs = self.codec.decode(local, overlap_seconds=overlap_seconds, device=self.device,
-                                 pad_to_length=t_max)["syn_wav_list"] if local else []
         up = self.codec.decoder_upsample_rate
         Lw = max(up * t_max, 1)
-        got = self._gather_rows_async(self._wav_rows(wavs, clen, a, b, Lw), parts, Lw, torch.float32).wait()
+        if hasattr(self.codec, "decode_padded"):
+            local = mine.view(b - a, G, Lc).permute(1, 0, 2) if b > a else None  # (G, rows, Lc) view of the received rows
+        else:
+            local = [mine[(i - a) * G:(i - a + 1) * G, : clen[i]] for i in range(a, b)]
+        rows = self._local_decode(local, clen, a, b, t_max, overlap_seconds, Lw)
+        got = self._gather_rows_async(rows, parts, Lw, torch.float32).wait()
         if self.rank != 0:
             return None
         return {"syn_wav_list": self._split_wavs(got, parts, clen)}
@@ -245,9 +275,8 @@ class DataParallelCodec:
         a, b = parts[self.rank]
         cparts = [(pa * G, pb * G) for pa, pb in parts]
         pend_codes = self._gather_rows_async(self._codes_rows(codes, clen, a, b, Lc), cparts, Lc, torch.int32)
-        wavs = self.codec.decode(codes, overlap_seconds=overlap_seconds, device=self.device,
-                                 pad_to_length=t_max)["syn_wav_list"] if codes else []
-        pend_wavs = self._gather_rows_async(self._wav_rows(wavs, clen, a, b, Lw), parts, Lw, torch.float32)
+        rows = self._local_decode(codes, clen, a, b, t_max, overlap_seconds, Lw)
+        pend_wavs = self._gather_rows_async(rows, parts, Lw, torch.float32)
         got_c = pend_codes.wait()
         got_w = pend_wavs.wait()
         if self.rank != 0:
