@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 import yaml
 
-from . import ops, spec, trace
+from . import ops, packed, spec, trace
 from ._lib import SwcError
 
 # precision presets: (encode-side GEMM operands, decode-side GEMM operands)
@@ -94,14 +94,23 @@ class _PW:
         return self.w.shape
 
 
+_PACK_CLASSES = {"Packed": _Packed, "PW": _PW, "Layer": _Layer}
+
+
 def _fold_wn(sd, p):
     g, v = sd[p + ".weight_g"], sd[p + ".weight_v"]
     nrm = v.reshape(v.shape[0], -1).norm(dim=1).view(-1, 1, 1)
     return g * v / nrm
 
 
+def _config_digest(gp):
+    import hashlib
+    import json
+    return hashlib.sha256(json.dumps(gp, sort_keys=True, default=str).encode()).hexdigest()[:16]
+
+
 class AudioCodec(nn.Module):
-    def __init__(self, generator_params, precision="mixed"):
+    def __init__(self, generator_params, precision="mixed", _packed_file=None):
         super().__init__()
         gp = generator_params
         self.generator_params = gp
@@ -128,8 +137,14 @@ class AudioCodec(nn.Module):
         if gp["vocos"]["n_fft"] != 640 or gp["vocos"]["hop_size"] != 160 or gp["vocos"].get("padding", "same") != "same":
             raise SwcError("the ISTFT kernels are built for n_fft 640 / hop 160 / 'same' padding")
         self.precision = precision
-        for name, (shape, dtype) in spec.state_shapes(gp).items():
-            _register(self, name, torch.zeros(shape, dtype=dtype))
+        # a model built from a packed-operand file (tools/pack_checkpoint.py --fold) holds no state_dict tensors: its
+        # operands go file -> device on first use; one anchor buffer keeps .to(device) / device tracking working
+        self._packed_file = _packed_file
+        if _packed_file is None:
+            for name, (shape, dtype) in spec.state_shapes(gp).items():
+                _register(self, name, torch.zeros(shape, dtype=dtype))
+        else:
+            self.register_buffer("_anchor", torch.zeros(1))
         self._pk = None
         self._pk_key = None
 
@@ -142,6 +157,9 @@ class AudioCodec(nn.Module):
     def precision(self, p):
         if p not in PRECISIONS:
             raise ValueError(f"precision must be one of {PRECISIONS}")
+        if getattr(self, "_packed_file", None) is not None and p != getattr(self, "_precision", p):
+            raise SwcError(f"this model was loaded from operands packed for precision={self._precision!r} "
+                           f"({self._packed_file}); pack the checkpoint again for {p!r} or load the .pt")
         self._precision = p
         self._pk = None
 
@@ -150,6 +168,8 @@ class AudioCodec(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
+        if self._packed_file is not None:
+            raise SwcError("a model built from a packed-operand file has no state_dict tensors to load into")
         self._pk = None
         return super().load_state_dict(*a, **k)
 
@@ -164,6 +184,12 @@ class AudioCodec(nn.Module):
         logging.info(f"Loading model from {config_path} and {ckpt_path}")
         with open(config_path, "r") as f:
             config = yaml.safe_load(f)
+        if str(ckpt_path).endswith(".safetensors"):
+            meta = packed.peek(ckpt_path)
+            if meta is not None:  # tools/pack_checkpoint.py --fold: GEMM-ready operands of one precision preset
+                if meta["config"] != _config_digest(config["generator_params"]):
+                    raise SwcError(f"{ckpt_path} was packed for another configuration than {config_path}")
+                return cls(config["generator_params"], precision=meta["precision"], _packed_file=str(ckpt_path))
         model = cls(config["generator_params"])
         if str(ckpt_path).endswith(".safetensors"):  # tools/pack_checkpoint.py output: same keys, no pickle
             from safetensors.torch import load_file
@@ -258,9 +284,23 @@ class AudioCodec(nn.Module):
         key = (dev, self._precision)
         if self._pk is not None and self._pk_key == key:
             return self._pk
-        self._pk = self._pack(dev)
+        if self._packed_file is not None:
+            self._pk, meta = packed.load(self._packed_file, dev, _PACK_CLASSES)
+            if meta["precision"] != self._precision or meta["abi"] != ops.abi_version():
+                raise SwcError(f"{self._packed_file}: packed for precision {meta['precision']} / library ABI {meta['abi']}, "
+                               f"this is {self._precision} / {ops.abi_version()}: pack the checkpoint again")
+        else:
+            self._pk = self._pack(dev)
         self._pk_key = key
         return self._pk
+
+    def export_packed(self, path):
+        """Write this model's GEMM-ready operands (current precision preset, current device) to a packed-operand
+        .safetensors file that load_from_checkpoint() maps straight to the device (tools/pack_checkpoint.py --fold)."""
+        P = self._packed()
+        torch.cuda.synchronize(self._buffers_device())
+        meta = {"precision": self._precision, "config": _config_digest(self.generator_params), "abi": ops.abi_version()}
+        return packed.save(path, P, _PACK_CLASSES, meta)
 
     @torch.no_grad()
     def _pack(self, dev):

@@ -297,3 +297,7 @@ def convnext_mlp(y, w_stream, b1, b2, gamma, x, *, M, C_, I):
     if prof is not None:
         prof.end()
     return x
+
+
+def abi_version():
+    return int(_lib.load().swc_version())

@@ -166,3 +166,45 @@ def test_tokenize_length_beyond_the_row():
     a = m.inference_tokenize(w.view(1, 1, -1), torch.tensor([16000]))
     b = m.inference_tokenize(w.view(1, 1, -1), torch.tensor([999999]))
     assert torch.equal(a["codes"], b["codes"]) and torch.equal(a["codes_lengths"], b["codes_lengths"])
+
+
+@pytest.mark.parametrize("precision", ["mixed", "fp8"])
+def test_packed_operand_checkpoint_is_identical(tmp_path, precision):
+    """tools/pack_checkpoint.py --fold: a model loaded from the packed-operand file never runs the fold /
+    scale / cast pass and must give bit-identical codes and waveforms to the model loaded from the reference layout."""
+    import subprocess, sys, yaml
+    from audiocodec.model import AudioCodec
+    from simwhisper_codec_amd import synth
+    from simwhisper_codec_amd._lib import SwcError
+    from common import ROOT
+    import os
+    gp = PARAMS["tiny"]()
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(yaml.safe_dump({"generator_params": gp}))
+    torch.save(state_dict("tiny"), tmp_path / "ref.pt")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pack_checkpoint.py"), "--config", str(cfg), "--in",
+                        str(tmp_path / "ref.pt"), "--fold", "--precision", precision, "--out", str(tmp_path / "pk.safetensors")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-1500:]
+    a = AudioCodec.load_from_checkpoint(str(cfg), str(tmp_path / "ref.pt"))
+    a.precision = precision
+    a = a.to(DEV).eval()
+    b = AudioCodec.load_from_checkpoint(str(cfg), str(tmp_path / "pk.safetensors")).to(DEV).eval()
+    assert b.precision == precision and len(list(b.buffers())) == 1  # no state_dict tensors were built or moved
+    called = []
+    b._pack = lambda dev: called.append(1)
+    wavs = [synth.synth_audio(30000 + 777 * i, index=900 + i, kind="speech" if i % 2 else "noise").to(DEV) for i in range(3)]
+    ca, cb = a.encode(wavs)["codes_list"], b.encode(wavs)["codes_list"]
+    wa, wb = a.decode(ca)["syn_wav_list"], b.decode(cb)["syn_wav_list"]
+    assert not called
+    for x, y in zip(ca + wa, cb + wb):
+        assert torch.equal(x, y)
+    with pytest.raises(SwcError, match="packed for precision"):
+        b.precision = "fp32"
+    # a packed file is bound to its configuration
+    gp2 = PARAMS["tiny"]()
+    gp2["vocos"]["num_layers"] = 2
+    cfg2 = tmp_path / "cfg2.yaml"
+    cfg2.write_text(yaml.safe_dump({"generator_params": gp2}))
+    with pytest.raises(SwcError, match="another configuration"):
+        AudioCodec.load_from_checkpoint(str(cfg2), str(tmp_path / "pk.safetensors"))

@@ -182,3 +182,32 @@ def test_product_never_imports_oracle():
             "simwhisper_codec_amd.wavio, audiocodec.model; "
             "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)" % ROOT)
     subprocess.run([sys.executable, "-c", code], check=True)
+
+
+def test_packed_operand_file_roundtrip(tmp_path):
+    """packed.py: nested operand structure -> safetensors (+ JSON skeleton) -> same structure, header-only peek."""
+    from simwhisper_codec_amd import packed
+    from simwhisper_codec_amd.codec import _PACK_CLASSES, _Layer, _PW, _Packed
+    P = _Packed()
+    P.edt, P.lat, P.fsq = torch.float16, 32, [3.4965, 0.5, 0.14398292]
+    L = _Layer()
+    L.wqkv, L.bqkv = _PW(torch.arange(12, dtype=torch.float32).view(3, 4).to(torch.bfloat16), 0.25), torch.ones(3)
+    L.ln1 = (torch.zeros(4), torch.ones(4))
+    P.layers = [L]
+    P.blocks = [dict(dw=torch.randn(7, 4), ws=torch.arange(16, dtype=torch.uint8), f0=[0.1, 0.2],
+                     w8=torch.randn(4, 4).to(torch.float8_e4m3fn))]
+    n, nbytes = packed.save(str(tmp_path / "p.safetensors"), P, _PACK_CLASSES, {"precision": "mixed", "config": "abc", "abi": 200})
+    assert n == 7 and nbytes > 0  # wqkv.w, bqkv, ln1 x2, dw, ws, w8
+    assert packed.peek(str(tmp_path / "p.safetensors")) == {"precision": "mixed", "config": "abc", "abi": 200}
+    Q, meta = packed.load(str(tmp_path / "p.safetensors"), "cpu", _PACK_CLASSES)
+    assert meta["precision"] == "mixed" and Q.edt == torch.float16 and Q.lat == 32 and Q.fsq == P.fsq
+    assert isinstance(Q.layers[0], _Layer) and isinstance(Q.layers[0].wqkv, _PW) and Q.layers[0].wqkv.alpha == 0.25
+    assert torch.equal(Q.layers[0].wqkv.w, L.wqkv.w) and Q.layers[0].wqkv.w.dtype == torch.bfloat16
+    assert isinstance(Q.layers[0].ln1, tuple) and torch.equal(Q.layers[0].ln1[1], torch.ones(4))
+    b = Q.blocks[0]
+    assert torch.equal(b["dw"], P.blocks[0]["dw"]) and torch.equal(b["ws"], P.blocks[0]["ws"]) and b["f0"] == [0.1, 0.2]
+    assert b["w8"].dtype == torch.float8_e4m3fn and torch.equal(b["w8"].view(torch.uint8), P.blocks[0]["w8"].view(torch.uint8))
+    # a plain state_dict safetensors file is not mistaken for a packed one
+    from safetensors.torch import save_file
+    save_file({"a": torch.zeros(2)}, str(tmp_path / "plain.safetensors"))
+    assert packed.peek(str(tmp_path / "plain.safetensors")) is None

@@ -1,12 +1,20 @@
 #!/usr/bin/env python3
-"""Checkpoint conversion: validate a reference `.pt` against the 711-key manifest of the
-YAML config and write it back as a flat safetensors file (no pickle: loads with zero code execution and
-memory-maps), optionally with weight norm already folded.
+"""Checkpoint conversion: validate a reference `.pt` against the 711-key manifest of the YAML config and
+write it as safetensors (no pickle: loads with zero code execution and memory-maps), in one of two forms:
+
+  plain (default)   the same 711 tensors; `load_from_checkpoint` then folds / scales / casts them at first use as for a `.pt`
+  --fold            GEMM-READY OPERANDS of one precision preset (needs the GPU: the packing kernels run once, here):
+                    weight norm folded, conv kernels as [Cout][tap][Cin], frame-stack columns re-ordered, per-tensor
+                    power-of-two scales, bf16 / split-f16 / e4m3 casts, the fused ConvNeXt operand streams, DFT / mel /
+                    inverse-DFT tables.  `load_from_checkpoint` maps this file straight to the device: no 12 s module
+                    construction, no fold / cast pass, no host synchronisation per tensor.  The file is bound to its
+                    precision preset, configuration and library ABI (checked at load).
 
     python tools/pack_checkpoint.py --config config/SimWhisperCodec.yaml --in weights/SimWhisperCodec.pt --out weights/SimWhisperCodec.safetensors
+    python tools/pack_checkpoint.py --config ... --in ... --fold --precision mixed --out weights/SimWhisperCodec.mixed.safetensors
     python tools/pack_checkpoint.py --config ... --synthetic --out /tmp/synth.safetensors
 
-`AudioCodec.load_from_checkpoint` accepts both `.pt` and `.safetensors` (same keys, strict)."""
+`AudioCodec.load_from_checkpoint` accepts `.pt` and both safetensors forms."""
 import argparse
 import os
 import sys
@@ -25,6 +33,9 @@ def main():
     ap.add_argument("--in", dest="inp", default=None)
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--fold", action="store_true", help="write GEMM-ready operands (needs the GPU)")
+    ap.add_argument("--precision", default="mixed", choices=["fp32", "mixed", "mixed_f32", "bf16", "fp8"])
+    ap.add_argument("--device", default="cuda:0")
     args = ap.parse_args()
     gp = yaml.safe_load(open(args.config))["generator_params"]
     if args.synthetic:
@@ -39,6 +50,15 @@ def main():
     for k, (shape, dtype) in want.items():
         if tuple(sd[k].shape) != shape:
             raise SystemExit(f"{k}: shape {tuple(sd[k].shape)} != {shape}")
+    if args.fold:
+        from simwhisper_codec_amd.codec import AudioCodec
+        m = AudioCodec(gp, precision=args.precision)
+        m.load_state_dict(sd, strict=True)
+        m = m.to(args.device).eval()
+        with torch.cuda.device(torch.device(args.device)):
+            nt, nbytes = m.export_packed(args.out)
+        print(f"wrote {args.out}: {nt} operand tensors, {nbytes / 1e6:.1f} MB, precision {args.precision}")
+        return
     from safetensors.torch import save_file
     save_file({k: v.contiguous() for k, v in sd.items()}, args.out, metadata={"format": "simwhisper-codec state_dict"})
     n = sum(v.numel() for v in sd.values())

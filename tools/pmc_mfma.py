@@ -12,7 +12,8 @@ import sys
 
 root = sys.argv[1]
 FAM = [("gemm_kernel<0", "gemm_f32"), ("gemm_kernel<1", "gemm_bf16"), ("gemm_kernel<2", "gemm_f16s"),
-       ("attn16_kernel<1>", "attention_bf16"), ("attn16_kernel<2>", "attention_f16s")]
+       ("attn16_kernel<1>", "attention_bf16"), ("attn16_kernel<2>", "attention_f16s"),
+       ("convnext_mlp_kernel", "convnext_bf16")]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.Counter()
 for f in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):
@@ -29,4 +30,5 @@ for fam, c in acc.items():
     out[fam] = {"mfma_busy_cycles": busy, "gui_active_cycles_per_xcd": active, "launches": n[fam],
                 "implied_clock_ghz": round(active / c["duration_ns"], 3) if c.get("duration_ns") else None,
                 "mfma_pipe_utilisation": round(busy / (active * 1024), 4) if active else None}
+    # busy cycles: 16 per 16x16x32 and 32 per 32x32x16 16-bit MFMA, summed over SIMDs
 print(json.dumps(out, indent=1))

@@ -9,7 +9,10 @@ import json
 import sys
 
 root = sys.argv[1]
-FAM = {"gemm_kernel<0": "gemm_f32", "gemm_kernel<1": "gemm_bf16", "gemm_kernel<2": "gemm_f16s", "gemm_kernel<3": "gemm_fp8"}
+FAM = {"gemm_kernel<0": "gemm_f32", "gemm_kernel<1": "gemm_bf16", "gemm_kernel<2": "gemm_f16s", "gemm_kernel<3": "gemm_fp8",
+       "convnext_mlp_kernel": "convnext_bf16", "dwconv7_ln_kernel": "dwconv7_ln", "attn16_kernel<1>": "attention_bf16",
+       "attn16_kernel<2>": "attention_f16s", "layernorm_kernel": "layernorm", "snake_aa_kernel": "snake_aa",
+       "istft_ola_kernel": "istft_ola", "mel_frames_kernel": "mel_frames"}
 
 
 def collect(sub, counter):
@@ -33,4 +36,11 @@ for fam in sorted(set(rd) | set(wr)):
                 "launches_sampled": len(rd[fam]),
                 "note": "FETCH_SIZE x 1024 x 2 (gfx950 half-count correction for wide coalesced reads) + WRITE_SIZE x 1024; "
                         "separate --pmc passes of `bench.py --steps 2 --warmup 1` (tools/pmc_traffic.sh)"}
+import os, subprocess
+try:
+    out["_commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                    text=True).stdout.strip() or os.environ.get("SWC_COMMIT")
+except Exception:
+    out["_commit"] = os.environ.get("SWC_COMMIT")
+out["_profile"] = os.environ.get("SWC_PROFILE_TAG", os.path.basename(os.path.normpath(root)))
 print(json.dumps(out, indent=1))
