@@ -222,7 +222,8 @@ class AudioCodec(nn.Module):
     # "fallback": an encode whose split-f16 operands clipped (|activation| >= 1023: possible with trained Whisper-style
     #             outlier channels, never seen with the synthetic checkpoint) is re-run on exact-f32 operands and the
     #             model stays on `mixed_f32` from then on — the codes equal the reference's either way;
-    # "raise":    SwcError instead; "ignore": count only (saturation_count()).
+    # "raise":    SwcError instead; "ignore": count only (saturation_count()); "off": the counters are not read back at
+    #             all (no stream synchronisation inside encode; for checkpoints whose range is known).
     saturation_policy = "fallback"
 
     def _sat_state(self, dev):
@@ -245,15 +246,33 @@ class AudioCodec(nn.Module):
         n = st["host"].tolist()
         return {"f16s": int(n[0]), "fp8": int(n[1])}
 
-    def _guarded_encode(self, run):
-        """run(P) enqueues the encode-side kernels of one call and returns its outputs.  After it, the clip counters are
-        read back (one 8-byte copy + stream sync per call; presets without reduced-range encode operands skip it)."""
-        P = self._packed()  # raises for a model that is not on the HIP device
+    class _Deferred:
+        """`with model.deferred_range_check() as chk:` — inside, encode-side calls do not read the clip counters back (no
+        stream synchronisation between encode and the work enqueued after it); leaving the block reads them once.
+        chk.clipped is then True when split-f16 operands clipped: with policy "fallback" the model has switched to exact-f32
+        encoder operands and THE CALLER MUST REDO the block (its codes are not reliable); "raise" raises here."""
+
+        def __init__(self, model):
+            self.m, self.clipped = model, False
+
+        def __enter__(self):
+            self.m.__dict__["_defer"] = self.m.__dict__.get("_defer", 0) + 1
+            return self
+
+        def __exit__(self, et, ev, tb):
+            self.m.__dict__["_defer"] -= 1
+            if et is None and self.m.__dict__["_defer"] == 0 and self.m.__dict__.pop("_defer_pending", False):
+                self.clipped = self.m._check_clipping()
+            return False
+
+    def deferred_range_check(self):
+        return AudioCodec._Deferred(self)
+
+    def _check_clipping(self):
+        """Read the counters (synchronises), apply the policy.  True: split-f16 operands clipped since the last check and the
+        model switched to exact-f32 encoder operands (policy "fallback"): the caller re-runs."""
         e = PRECISIONS[self._precision][0]
-        if e != "f16s" and self._precision != "fp8":
-            return run(P)
         st = self._sat_state(self._buffers_device())
-        out = run(P)
         n = self.saturation_count()
         new16, new8 = n["f16s"] - st["seen"][0], n["fp8"] - st["seen"][1]
         st["seen"] = [n["f16s"], n["fp8"]]
@@ -269,7 +288,22 @@ class AudioCodec(nn.Module):
                 logging.warning("split-f16 operands clipped (%d producer threads saw |activation| >= 1023): re-running this "
                                 "call on exact-f32 encoder operands; the model stays on precision='mixed_f32'", new16)
                 self.precision = "mixed_f32" if self._precision == "mixed" else "fp32"
-                out = run(self._packed())
+                return True
+        return False
+
+    def _guarded_encode(self, run):
+        """run(P) enqueues the encode-side kernels of one call and returns its outputs.  After it, the clip counters are
+        read back (one 8-byte copy + stream sync per call; presets without reduced-range encode operands skip it)."""
+        P = self._packed()  # raises for a model that is not on the HIP device
+        e = PRECISIONS[self._precision][0]
+        if (e != "f16s" and self._precision != "fp8") or self.saturation_policy == "off":
+            return run(P)
+        out = run(P)
+        if self.__dict__.get("_defer", 0) > 0:  # inside deferred_range_check(): one read-back when the block ends
+            self.__dict__["_defer_pending"] = True
+            return out
+        if self._check_clipping():
+            out = run(self._packed())
         return out
 
     # ------------------------------------------------------------- packing

@@ -8,6 +8,7 @@
 #include "swc.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short bf16_t;  // raw bf16 storage
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));

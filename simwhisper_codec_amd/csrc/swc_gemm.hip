@@ -388,7 +388,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         if (kt + 1 < nkt) stage_slice(kt + 1, cur ^ 1);
         const char* sa = smem + cur * STAGE_BYTES;
         const char* sb = sa + A_BYTES;
-        uint4 ha[F16S ? MT : 1], hb[F16S ? 4 : 1];
+        uint4 ha[(F16S || FP8) ? MT : 1], hb[(F16S || FP8) ? 4 : 1];  // first 16-byte chunk of a fragment, kept until the second is read
         (void)ha; (void)hb;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -430,19 +430,30 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             *reinterpret_cast<bf16x8*>(&fb[j]), *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
             } else if constexpr (FP8) {
-                // a 16-byte chunk is 16 e4m3 k-values: its low and high 8 bytes feed two 16x16x32 steps (the k order
-                // inside the slice is permuted identically for both operands)
+                // Block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3): K = 128 per instruction at twice the
+                // bf16 rate per clock — the non-scaled fp8 MFMA runs at the bf16 rate.  Lane (fr, fh) supplies 32 bytes of
+                // its row: the two 16-byte chunks fh and fh + 4 of the 128-byte slice (the k order inside the slice is
+                // the same permutation for both operands; layout probed on hardware, tools/probes/mx_mfma_layout_probe.hip).
+                // Scales: E8M0 bytes, 0x7f = 2^0 for every 32-block (the power-of-two tensor scales live in `alpha`).
+                if (g == 0) {
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                    for (int i = 0; i < MT; ++i) ha[i] = fa[i];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f32x4 c = acc[i][j];
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(reinterpret_cast<const long*>(&fb[j])[0],
-                                                                        reinterpret_cast<const long*>(&fa[i])[0], c, 0, 0, 0);
-                        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(reinterpret_cast<const long*>(&fb[j])[1],
-                                                                        reinterpret_cast<const long*>(&fa[i])[1], c, 0, 0, 0);
-                        acc[i][j] = c;
-                    }
+                    for (int j = 0; j < 4; ++j) hb[j] = fb[j];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            i32x8 wa, xa;
+                            wa[0] = hb[j].x; wa[1] = hb[j].y; wa[2] = hb[j].z; wa[3] = hb[j].w;
+                            wa[4] = fb[j].x; wa[5] = fb[j].y; wa[6] = fb[j].z; wa[7] = fb[j].w;
+                            xa[0] = ha[i].x; xa[1] = ha[i].y; xa[2] = ha[i].z; xa[3] = ha[i].w;
+                            xa[4] = fa[i].x; xa[5] = fa[i].y; xa[6] = fa[i].z; xa[7] = fa[i].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                                         0x7f7f7f7f);
+                        }
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)

@@ -148,12 +148,16 @@ class DataParallelCodec:
         return out
 
     def _local_encode(self, wav_list, lens, parts, overlap_seconds):
-        """scatter + this rank's encode.  Returns its codes as a padded (G, rows, Lc') tensor (codecs with the batch entry
-        points encode_padded / decode_padded: no per-utterance tensors at all) or as a list of (G, T_i) tensors."""
+        """scatter + this rank's encode (see _encode_rows)."""
         L = max(lens) if lens else 0
         batch = self._pad_batch(wav_list, lens, torch.float32) if self.rank == 0 else None
         mine = self._scatter_rows(batch, parts, max(L, 1) if lens else 0, torch.float32)
         a, b = parts[self.rank]
+        return self._encode_rows(mine, lens, a, b, overlap_seconds)
+
+    def _encode_rows(self, mine, lens, a, b, overlap_seconds):
+        """this rank's encode of its received rows.  Returns the codes as a padded (G, rows, Lc') tensor (codecs with the
+        batch entry points encode_padded / decode_padded: no per-utterance tensors at all) or as a list of (G, T_i) tensors."""
         if b == a:
             return []
         if hasattr(self.codec, "encode_padded"):
@@ -267,15 +271,30 @@ class DataParallelCodec:
         if not lens:
             return {"codes_list": [], "syn_wav_list": []} if self.rank == 0 else None
         parts = partition(lens, self.world)
-        codes = self._local_encode(wav_list, lens, parts, overlap_seconds)
         rate, up, G = self.codec.encoder_downsample_rate, self.codec.decoder_upsample_rate, self.codec.num_groups
         clen = [l // rate for l in lens]
         t_max = max(clen)
         Lc, Lw = max(t_max, 1), max(up * t_max, 1)
         a, b = parts[self.rank]
         cparts = [(pa * G, pb * G) for pa, pb in parts]
+        L = max(lens)
+        batch = self._pad_batch(wav_list, lens, torch.float32) if self.rank == 0 else None
+        mine = self._scatter_rows(batch, parts, max(L, 1), torch.float32)
+
+        def local_round_trip():
+            codes = self._encode_rows(mine, lens, a, b, overlap_seconds)
+            return codes, self._local_decode(codes, clen, a, b, t_max, overlap_seconds, Lw)
+        # the operand-range check of the split-f16 encoder is read back ONCE, after the decode has been enqueued (no stall
+        # between encode and decode); if operands clipped the codec has switched to exact-f32 operands and the shard is redone
+        defer = getattr(self.codec, "deferred_range_check", None)
+        if defer is not None:
+            with defer() as chk:
+                codes, rows = local_round_trip()
+            if chk.clipped:
+                codes, rows = local_round_trip()
+        else:
+            codes, rows = local_round_trip()
         pend_codes = self._gather_rows_async(self._codes_rows(codes, clen, a, b, Lc), cparts, Lc, torch.int32)
-        rows = self._local_decode(codes, clen, a, b, t_max, overlap_seconds, Lw)
         pend_wavs = self._gather_rows_async(rows, parts, Lw, torch.float32)
         got_c = pend_codes.wait()
         got_w = pend_wavs.wait()

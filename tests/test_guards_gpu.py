@@ -208,3 +208,31 @@ def test_packed_operand_checkpoint_is_identical(tmp_path, precision):
     cfg2.write_text(yaml.safe_dump({"generator_params": gp2}))
     with pytest.raises(SwcError, match="another configuration"):
         AudioCodec.load_from_checkpoint(str(cfg2), str(tmp_path / "pk.safetensors"))
+
+
+def test_deferred_range_check_redo():
+    """deferred_range_check(): no read-back (no stream sync) between encode and decode; one read-back when the block ends;
+    on clipping the model has switched to exact-f32 operands and the redone block gives the reference's codes."""
+    from oracle.ref_cpu import Oracle
+    from simwhisper_codec_amd import synth
+    tag = "tiny"
+    sd = _outlier_state_dict(tag)
+    wavs = [synth.synth_audio(30000, index=300, kind="speech"), synth.synth_audio(21111, index=301, kind="noise")]
+    want = Oracle(PARAMS[tag](), sd).encode(wavs, trim=True)["codes_list"]
+    m = _model(tag, "mixed", sd)
+    dw = [w.to(DEV) for w in wavs]
+    with m.deferred_range_check() as chk:
+        c = m.encode(dw)["codes_list"]
+        assert m.precision == "mixed"          # nothing was read back yet
+        m.decode(c)
+    assert chk.clipped and m.precision == "mixed_f32"
+    with m.deferred_range_check() as chk2:
+        c = m.encode(dw)["codes_list"]
+        m.decode(c)
+    assert not chk2.clipped
+    for a, b in zip(c, want):
+        assert torch.equal(a.cpu().long(), b.long())
+    m2 = _model(tag, "mixed")               # the plain checkpoint: nothing clips, nothing changes
+    with m2.deferred_range_check() as chk3:
+        m2.decode(m2.encode(dw)["codes_list"])
+    assert not chk3.clipped and m2.precision == "mixed"

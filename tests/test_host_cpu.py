@@ -16,7 +16,7 @@ def test_library_exports_every_declared_symbol():
     build.build_library()
     lib = _lib.load()
     hdr = open(os.path.join(ROOT, "include", "swc.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(swc_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(swc_\w+)\s*\(", hdr, flags=re.M))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
     for name in declared:
