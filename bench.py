@@ -128,6 +128,21 @@ def cpu_baseline(gp, sd, shapes, seconds, threads):
             "shapes": res}
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on stdout when its communicator is created; the bench's stdout carries one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def git_commit():
     try:
         return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE,
@@ -168,8 +183,11 @@ def main():
                 s = socket.socket(); s.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s.getsockname()[1]); s.close()
             import datetime
             # a failed peer must not leave the others waiting for the default 10 minutes
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
-                                    timeout=datetime.timedelta(seconds=240))
+            with _StdoutToStderr():
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                        timeout=datetime.timedelta(seconds=240))
+                dist.barrier()  # creates the communicator now (and prints RCCL's banner to stderr)
+                torch.cuda.synchronize(dev)
             use_dist = True
         except Exception as e:  # a single GPU still has its number; N > 1 cannot run without the group
             if world > 1:

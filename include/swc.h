@@ -164,6 +164,17 @@ int64_t swc_convnext_stream_bytes(int32_t C, int32_t I);
 int swc_convnext_pack(const void* w1_bf16, const void* w2_bf16, void* w_stream, int32_t C, int32_t I, void* stream);
 int swc_convnext_mlp(const void* y, const void* w_stream, const float* b1, const float* b2, const float* gamma,
                      float* x, int32_t M, int32_t C, int32_t I, void* stream);
+/*
+ * The WHOLE ConvNeXtBlock.forward (modules.py:1229-1248) in one kernel: the workgroup also computes the front half
+ * (depthwise Conv1d k7 pad 3 + LayerNorm(eps), the arithmetic of swc_dwconv7_ln) of its 128 frames, so the bf16 copy of the
+ * normalised activations never exists in memory either: per block the residual stream x [B][T][C] f32 is read (+6 halo rows
+ * per 128) and x_out written once.  NOT in place (x_out != x: tiles read halo rows of their neighbours, which a finished
+ * neighbour would already have updated); the caller ping-pongs two buffers over the 24 blocks.  dw_w7: [7][C], taps do
+ * not cross utterances (rows b * T + t).  Same geometry limits.
+ */
+int swc_convnext_block(const float* x, float* x_out, const float* dw_w7, const float* dw_bias, const float* ln_w,
+                       const float* ln_b, float eps, const void* w_stream, const float* b1, const float* b2,
+                       const float* gamma, int32_t B, int32_t T, int32_t C, int32_t I, void* stream);
 
 /*
  * ConvNeXt front half: depthwise Conv1d(k=7, pad=3, groups=C) + LayerNorm(eps)

@@ -640,11 +640,14 @@ class AudioCodec(nn.Module):
         # one fused kernel per block when the grid fills the chip (128-frame tiles, one per CU); small batches keep the
         # two-GEMM form, whose 128 x 128 tiles spread over more CUs
         fused = P.fused_mlp and M >= self.fused_mlp_min_rows
+        x2 = torch.empty_like(x) if fused else None  # the fused block is not in place: two buffers alternate
         for blk in P.blocks:
-            y = ops.dwconv7_ln(x, blk["dw"], blk["db"], blk["ln"][0], blk["ln"][1], 1e-6, B=B, T=Tv, C_=C, out_dtype=dt)
-            if fused:
-                ops.convnext_mlp(y, blk["ws"], blk["b1"], blk["b2"], blk["g"], x, M=M, C_=C, I=P.vint)
+            if fused:  # the whole block (depthwise conv + LayerNorm + MLP + residual) is one kernel
+                ops.convnext_block(x, x2, blk["dw"], blk["db"], blk["ln"][0], blk["ln"][1], 1e-6, blk["ws"], blk["b1"],
+                                   blk["b2"], blk["g"], B=B, T=Tv, C_=C, I=P.vint)
+                x, x2 = x2, x
                 continue
+            y = ops.dwconv7_ln(x, blk["dw"], blk["db"], blk["ln"][0], blk["ln"][1], 1e-6, B=B, T=Tv, C_=C, out_dtype=dt)
             y = self._mm(y, blk["w1"], M, P.vint, C, lda=C, bias=blk["b1"], act=ops.ACT_GELU, out_dtype=dt)
             self._mm(y, blk["w2"], M, C, P.vint, lda=P.vint, bias=blk["b2"], gamma=blk["g"], residual=x, out=x)
         hn = ops.layernorm(x, P.vfin[0], P.vfin[1], 1e-6, B=B, t_in=Tv, C_=C, out_dtype=dt)

@@ -160,4 +160,21 @@ __device__ __forceinline__ float gelu_as(float x) {
         }                                                                                                   \
     } while (0)
 
+// Sum over the 64 lanes on the DPP path (no LDS crossbar round trips): xor 1, xor 2, half-row mirror and row
+// mirror leave each row of 16 lanes holding its row sum; row_bcast:15 / row_bcast:31 chain the four rows into
+// lane 63, which is read into an SGPR (the result is wave-uniform).  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);  // row_mirror
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -74,11 +74,25 @@ __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, f32x16 
                                                    c, 0, 0, 0);
 }
 
+// front half of the block for the fused form: depthwise Conv1d(k7, pad 3, per utterance) + LayerNorm (modules.py:1233-1239)
+struct CxFront {
+    const float* w7;    // [7][C] depthwise taps
+    const float* bias;  // [C]
+    const float* ln_w;  // [C]
+    const float* ln_b;  // [C]
+    int T;              // frames per utterance: rows b * T + t; taps do not cross utterances (zero padding)
+    float eps;
+};
+
 // wstream: per wave w (4 of them) NS * 64 + CX_PF fragments of 1 KiB in the order of consumption (swc_convnext_pack)
+// FUSED_DW: y is not read; the workgroup computes LayerNorm(dwconv7(x)) of its 128 frames itself (front half above)
+template <bool FUSED_DW>
 __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __restrict__ y, const u32x4* __restrict__ wstream,
                                                              const float* __restrict__ b1, const float* __restrict__ b2,
-                                                             const float* __restrict__ gamma, float* __restrict__ x, int M,
-                                                             int NS) {
+                                                             const float* __restrict__ gamma, const float* x, float* xo,
+                                                             int M, int NS, CxFront fr) {
+    // x: residual stream in (front half incl. halo rows of the neighbouring tiles, and the residual add); xo: residual
+    // stream out.  The fused form must not run in place: a later tile would read halo rows an earlier tile has updated.
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -89,7 +103,7 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
     // ---- y tile -> LDS as B fragments: fragment (s, fb) = k-step s (16 channels) x frame block fb (32 frames) at
     // [(4 s + fb)][lane][16 B]; lane l supplies frame 32 fb + (l & 31), channels 16 s + 8 (l >> 5) .. + 7.  LDS-DMA with a
     // per-lane source address writes exactly this lane-linear image.
-    {
+    if constexpr (!FUSED_DW) {
         const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
 #pragma unroll 4
         for (int i = 0; i < 32; ++i) {
@@ -100,6 +114,119 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
             cx_glds16(y + (long)row * CX_C + 16 * s + 8 * lh, lds0 + frag * 1024);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        // Wave w turns out the 32 frames of frame block w: a lane owns channels 4 l .. 4 l + 3 and 256 + 4 l .. + 3 of
+        // every row (whole 2 KiB rows per wave load, LayerNorm sums on the DPP path, nothing crosses waves).  Groups of 4
+        // frames: their 10 input rows sit in registers, the 4 new rows of the next group are in flight meanwhile.
+        // Same arithmetic, in the same order, as swc_dwconv7_ln (bias, taps 0..6 as fma, two-pass LayerNorm).
+        const float4* x4 = reinterpret_cast<const float4*>(x);
+        float4 wr[7][2], br[2], gw[2], gb[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) wr[j][k] = reinterpret_cast<const float4*>(fr.w7 + (long)j * CX_C)[lane + 64 * k];
+            br[k] = reinterpret_cast<const float4*>(fr.bias)[lane + 64 * k];
+            gw[k] = reinterpret_cast<const float4*>(fr.ln_w)[lane + 64 * k];
+            gb[k] = reinterpret_cast<const float4*>(fr.ln_b)[lane + 64 * k];
+        }
+        const int f0w = row0 + 32 * w;  // first row of this wave
+        // Waves whose 38-row window lies inside one utterance and inside the tensor (all but one in ~8 at T = 1000) skip
+        // every boundary test: the tests are integer divisions on the scalar unit, 54 per group
+        const bool interior = f0w - 3 >= 0 && f0w + 35 < M && (f0w - 3) / fr.T == (f0w + 35) / fr.T;
+        auto load_row = [&](int r, float4 (&dst)[2]) {  // rows outside the tensor are zeros (wave-uniform test)
+            const bool ok = interior || (r >= 0 && r < M);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) dst[k] = ok ? x4[(long)r * (CX_C / 4) + lane + 64 * k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        // A row stays in the window for up to three groups and can be a valid tap for one frame and lie beyond an utterance
+        // boundary for another: rows are loaded as they are, the utterance test is made per (frame, row) pair when used.
+        float4 win[10][2], nxt[4][2];
+#pragma unroll
+        for (int p = 0; p < 10; ++p) load_row(f0w - 3 + p, win[p]);
+        const float inv_c = 1.0f / (float)CX_C;
+        char* ybase = smem;
+        for (int g = 0; g < 8; ++g) {
+            if (g + 1 < 8) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) load_row(f0w + 4 * (g + 1) + 3 + p, nxt[p]);
+            }
+            int ur[10], uf[4];  // utterance of every window row / frame of the group (boundary waves only)
+            if (!interior) {
+#pragma unroll
+                for (int p = 0; p < 10; ++p) {
+                    const int r = f0w + 4 * g - 3 + p;
+                    ur[p] = r < 0 ? -1 : r / fr.T;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) uf[u] = ur[u + 3];
+            }
+            float4 v[4][2];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) v[u][k] = br[k];
+#pragma unroll
+            for (int p = 0; p < 10; ++p)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = p - u;  // frame u takes window row p as tap j
+                    if (j >= 0 && j < 7) {
+                        const bool ok = interior || ur[p] == uf[u];  // same utterance (wave-uniform)
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const float4 xv = ok ? win[p][k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                            v[u][k].x += xv.x * wr[j][k].x; v[u][k].y += xv.y * wr[j][k].y;
+                            v[u][k].z += xv.z * wr[j][k].z; v[u][k].w += xv.w * wr[j][k].w;
+                        }
+                    }
+                }
+            float sum[4], sq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                sum[u] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) sum[u] += (v[u][k].x + v[u][k].y) + (v[u][k].z + v[u][k].w);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sum[u] = wave_sum_dpp(sum[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float mean = sum[u] * inv_c;
+                sq[u] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    v[u][k].x -= mean; v[u][k].y -= mean; v[u][k].z -= mean; v[u][k].w -= mean;
+                    sq[u] += (v[u][k].x * v[u][k].x + v[u][k].y * v[u][k].y) + (v[u][k].z * v[u][k].z + v[u][k].w * v[u][k].w);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sq[u] = wave_sum_dpp(sq[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float rstd = rsqrtf(sq[u] * inv_c + fr.eps);
+                const int fl = 4 * g + u;  // frame inside this wave's block
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float o0 = v[u][k].x * rstd * gw[k].x + gb[k].x, o1 = v[u][k].y * rstd * gw[k].y + gb[k].y;
+                    const float o2 = v[u][k].z * rstd * gw[k].z + gb[k].z, o3 = v[u][k].w * rstd * gw[k].w + gb[k].w;
+                    // channels c = 256 k + 4 l .. + 3 -> fragment (s = c / 16, fb = w), lane' = 32 ((c % 16) / 8) + frame,
+                    // byte (c % 8) * 2
+                    const int s_ = 16 * k + (lane >> 2);
+                    const int off = ((s_ * 4 + w) * 64 + 32 * ((lane >> 1) & 1) + fl) * 16 + (lane & 1) * 8;
+                    *reinterpret_cast<uint2*>(ybase + off) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+                }
+            }
+            // slide the window by 4 rows
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) win[p][k] = win[p + 4][k];
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) win[6 + p][k] = nxt[p][k];
+        }
         __syncthreads();
     }
     const u32x4* ylds = reinterpret_cast<const u32x4*>(smem) + lane;
@@ -271,11 +398,10 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const float4 v = *reinterpret_cast<const float4*>(tl + fl * CX_TLD + 256 * hf + 4 * lane);
-                    float4* xp = reinterpret_cast<float4*>(x + row * CX_C + 256 * hf + 4 * lane);
-                    float4 r = *xp;
+                    float4 r = *reinterpret_cast<const float4*>(x + row * CX_C + 256 * hf + 4 * lane);
                     r.x += g4[hf].x * (v.x + c4[hf].x); r.y += g4[hf].y * (v.y + c4[hf].y);
                     r.z += g4[hf].z * (v.z + c4[hf].z); r.w += g4[hf].w * (v.w + c4[hf].w);
-                    *xp = r;
+                    *reinterpret_cast<float4*>(xo + row * CX_C + 256 * hf + 4 * lane) = r;
                 }
             }
         }
@@ -349,11 +475,34 @@ extern "C" int swc_convnext_mlp(const void* y, const void* w_stream, const float
     SWC_CHECK_ARG(aligned16(y) && aligned16(w_stream) && aligned16(b1) && aligned16(b2) && aligned16(gamma) && aligned16(x),
                   "swc_convnext_mlp: unaligned");
     if (M == 0) return SWC_OK;
-    auto kern = convnext_mlp_kernel;
+    auto kern = convnext_mlp_kernel<false>;
     SWC_ENABLE_LDS(kern, CX_LDS, "swc_convnext_mlp");
     const unsigned grid = (unsigned)((M + CX_BM - 1) / CX_BM);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CX_LDS, (hipStream_t)stream, (const bf16_t*)y, (const u32x4*)w_stream,
-                       b1, b2, gamma, x, M, I / CX_SL);
+                       b1, b2, gamma, x, x, M, I / CX_SL, CxFront{});
     SWC_CHECK_LAUNCH("swc_convnext_mlp");
+    return SWC_OK;
+}
+
+extern "C" int swc_convnext_block(const float* x, float* x_out, const float* dw_w7, const float* dw_bias, const float* ln_w,
+                                  const float* ln_b, float eps, const void* w_stream, const float* b1, const float* b2,
+                                  const float* gamma, int32_t B, int32_t T, int32_t C, int32_t I, void* stream) {
+    SWC_CHECK_ARG(x && x_out && x != x_out, "swc_convnext_block: x and x_out must be two different buffers");
+    SWC_CHECK_ARG(x && dw_w7 && dw_bias && ln_w && ln_b && w_stream && b1 && b2 && gamma, "swc_convnext_block: null pointer");
+    SWC_CHECK_ARG(C == CX_C && I > 0 && I % CX_SL == 0, "swc_convnext_block: needs C = %d and I a multiple of %d (C=%d I=%d)",
+                  CX_C, CX_SL, C, I);
+    SWC_CHECK_ARG(B >= 0 && T >= 0 && (long)B * T < (1L << 31), "swc_convnext_block: bad B/T");
+    SWC_CHECK_ARG(aligned16(x) && aligned16(x_out) && aligned16(dw_w7) && aligned16(dw_bias) && aligned16(ln_w) && aligned16(ln_b) &&
+                      aligned16(w_stream) && aligned16(b1) && aligned16(b2) && aligned16(gamma),
+                  "swc_convnext_block: unaligned");
+    const int M = B * T;
+    if (M == 0) return SWC_OK;
+    auto kern = convnext_mlp_kernel<true>;
+    SWC_ENABLE_LDS(kern, CX_LDS, "swc_convnext_block");
+    const unsigned grid = (unsigned)((M + CX_BM - 1) / CX_BM);
+    CxFront fr{dw_w7, dw_bias, ln_w, ln_b, T, eps};
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CX_LDS, (hipStream_t)stream, (const bf16_t*)nullptr,
+                       (const u32x4*)w_stream, b1, b2, gamma, x, x_out, M, I / CX_SL, fr);
+    SWC_CHECK_LAUNCH("swc_convnext_block");
     return SWC_OK;
 }

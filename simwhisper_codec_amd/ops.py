@@ -301,3 +301,17 @@ def convnext_mlp(y, w_stream, b1, b2, gamma, x, *, M, C_, I):
 
 def abi_version():
     return int(_lib.load().swc_version())
+
+
+def convnext_block(x, x_out, w7, dw_bias, ln_w, ln_b, eps, w_stream, b1, b2, gamma, *, B, T, C_, I):
+    """One whole ConvNeXt block: residual stream x [B, T, C] f32 -> x_out (a different buffer; swc_convnext_block)."""
+    lib = _lib.load()
+    _chk(x, "convnext_block x", torch.float32); _chk(x_out, "convnext_block x_out", torch.float32)
+    prof = PROFILER
+    if prof is not None:
+        prof.begin("convnext_bf16", 4.0 * B * T * C_ * I)
+    _lib.check(lib.swc_convnext_block(_ptr(x), _ptr(x_out), _ptr(w7), _ptr(dw_bias), _ptr(ln_w), _ptr(ln_b), eps, _ptr(w_stream),
+                                      _ptr(b1), _ptr(b2), _ptr(gamma), B, T, C_, I, _stream()), "swc_convnext_block")
+    if prof is not None:
+        prof.end()
+    return x_out

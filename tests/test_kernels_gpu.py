@@ -683,3 +683,41 @@ def test_convnext_mlp_fused(M, I):
     assert e_ref < 1e-2, (e_ref, e_two_ref)        # bf16 intermediate: same class as the two-GEMM path
     assert e_ref < 2.0 * e_two_ref + 1e-4, (e_ref, e_two_ref)
     assert e_two < 5e-3, e_two
+
+
+@pytest.mark.parametrize("B,T,I", [(3, 100, 256), (2, 300, 512), (40, 125, 4096), (1, 5, 128)])
+def test_convnext_block_fused(B, T, I):
+    """swc_convnext_block (depthwise k7 + LayerNorm + MLP + residual in one kernel, out of place) vs the kernels it
+    replaces (swc_dwconv7_ln -> swc_convnext_mlp) and vs an f64 evaluation of ConvNeXtBlock.forward (modules.py:1229-1248).
+    Tiles straddle utterance boundaries (T not a multiple of 128): the taps must not cross them."""
+    ops = _ops()
+    C, M = 512, B * T
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x0 = torch.randn(B, T, C, generator=g)
+    w7, db = torch.randn(7, C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
+    lw, lb = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w1 = (torch.randn(I, C, generator=g) * C ** -0.5).to(torch.bfloat16)
+    w2 = (torch.randn(C, I, generator=g) * I ** -0.5).to(torch.bfloat16)
+    b1, b2, gam = torch.randn(I, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g)
+    d = lambda t: t.to(DEV)
+    ws = ops.convnext_pack(d(w1), d(w2))
+    xd = d(x0)
+    out = torch.full_like(xd, float("nan"))
+    ops.convnext_block(xd, out, d(w7), d(db), d(lw), d(lb), 1e-6, ws, d(b1), d(b2), d(gam), B=B, T=T, C_=C, I=I)
+    assert torch.equal(xd.cpu(), x0)  # the input buffer is read only
+    # the unfused pair
+    y = ops.dwconv7_ln(xd, d(w7), d(db), d(lw), d(lb), 1e-6, B=B, T=T, C_=C, out_dtype=torch.bfloat16)
+    x2 = xd.clone()
+    ops.convnext_mlp(y, ws, d(b1), d(b2), d(gam), x2, M=M, C_=C, I=I)
+    assert torch.isfinite(out).all()
+    # f64 reference of the block
+    xr = x0.double().transpose(1, 2)  # (B, C, T)
+    conv = F.conv1d(xr, w7.double().T.unsqueeze(1), db.double(), padding=3, groups=C).transpose(1, 2)
+    yn = F.layer_norm(conv, (C,), lw.double(), lb.double(), 1e-6)
+    h = F.gelu(yn @ w1.double().T + b1.double())
+    ref = x0.double() + gam.double() * (h @ w2.double().T + b2.double())
+    scale = float((ref - x0.double()).abs().max())
+    e_ref = float((out.cpu().double() - ref).abs().max()) / scale
+    e_pair = float((out.cpu().double() - x2.cpu().double()).abs().max()) / scale
+    assert e_ref < 1.5e-2, e_ref      # bf16 operands (y and the GELU output are rounded to bf16)
+    assert e_pair < 2e-3, e_pair      # same arithmetic as the two-kernel form up to the bf16 rounding of y at ties

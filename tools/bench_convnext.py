@@ -23,18 +23,40 @@ def fused(i):
     ops.convnext_mlp(ys[i % NB], ws, b1, b2, gam, xs[i % NB], M=M, C_=C, I=I)
 
 
+w7, db = torch.randn(7, C, device=dev) * 0.3, torch.randn(C, device=dev) * 0.1
+lw, lb = 1 + 0.2 * torch.randn(C, device=dev), 0.1 * torch.randn(C, device=dev)
+Bu, Tu = M // 1000 if M % 1000 == 0 else 1, 1000 if M % 1000 == 0 else M
+xo = [torch.empty(M, C, device=dev) for _ in range(2)]
+
+
+def block(i):  # the whole ConvNeXt block in one kernel (depthwise conv + LayerNorm included)
+    ops.convnext_block(xs[i % NB], xo[i % 2], w7, db, lw, lb, 1e-6, ws, b1, b2, gam, B=Bu, T=Tu, C_=C, I=I)
+
+
+def three(i):  # what the block was before: dwconv7_ln + two GEMMs
+    yy = ops.dwconv7_ln(xs[i % NB], w7, db, lw, lb, 1e-6, B=Bu, T=Tu, C_=C, out_dtype=torch.bfloat16)
+    ops.gemm(yy, w1, M, I, C, bias=b1, act=ops.ACT_GELU, out=hh)
+    ops.gemm(hh, w2, M, C, I, bias=b2, gamma=gam, residual=xs[i % NB], out=xs[i % NB])
+
+
+def dw_mlp(i):  # dwconv7_ln + fused MLP kernel
+    yy = ops.dwconv7_ln(xs[i % NB], w7, db, lw, lb, 1e-6, B=Bu, T=Tu, C_=C, out_dtype=torch.bfloat16)
+    ops.convnext_mlp(yy, ws, b1, b2, gam, xs[i % NB], M=M, C_=C, I=I)
+
+
 def two(i):
     ops.gemm(ys[i % NB], w1, M, I, C, bias=b1, act=ops.ACT_GELU, out=hh)
     ops.gemm(hh, w2, M, C, I, bias=b2, gamma=gam, residual=xs[i % NB], out=xs[i % NB])
 
 
-res = {"fused": [], "two_gemm": []}
-for fn in (fused, two):
+res = {"fused": [], "two_gemm": [], "block": [], "dw+mlp": [], "dw+2gemm": []}
+ALL = (("fused", fused), ("two_gemm", two), ("block", block), ("dw+mlp", dw_mlp), ("dw+2gemm", three))
+for _, fn in ALL:
     for i in range(3):
         fn(i)
 torch.cuda.synchronize()
 for rnd in range(7):
-    for name, fn in (("fused", fused), ("two_gemm", two)):
+    for name, fn in ALL:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for i in range(6):
