@@ -100,6 +100,74 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     sat_commit_out<OutT>(sat, amax);
 }
 
+// Two rows per wave, C == 256 * NV exactly (the path's 512 and 768): both rows' loads are in flight together, the four
+// reductions interleave, the affine parameters are read once for both rows, and the grid has half the workgroups.
+template <typename OutT, int NV>
+__global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ x, OutT* __restrict__ y,
+                                                         const float* __restrict__ w, const float* __restrict__ bia,
+                                                         const int* __restrict__ lens, long rows, int tw, int t_in,
+                                                         int t_out, float eps, unsigned* sat) {
+    constexpr int C = 256 * NV;
+    const int lane = threadIdx.x & 63;
+    const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (r0 >= rows) return;
+    const float* xr[2];
+    OutT* yr[2];
+    bool live[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const long r = r0 + u;
+        const bool in = r < rows;
+        const int b = in ? (int)(r / tw) : 0, t = in ? (int)(r - (long)b * tw) : 0;
+        xr[u] = x + ((long)b * t_in + t) * C;
+        yr[u] = y + ((long)b * t_out + t) * row_units<OutT>(C);
+        live[u] = in && t < t_in && !(lens && t >= lens[b]);
+        if (in && !live[u]) {  // masked rows and the zero extension beyond the input
+            float z_ = 0.f;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) store_row4<OutT>(yr[u], 4 * (lane + 64 * k), 0.f, 0.f, 0.f, 0.f, z_);
+        }
+    }
+    float4 v[2][NV];
+    float s[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            v[u][k] = live[u] ? *reinterpret_cast<const float4*>(xr[u] + 4 * (lane + 64 * k)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s[u] += (v[u][k].x + v[u][k].y) + (v[u][k].z + v[u][k].w);
+        }
+    float4 ww[NV], bb[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        ww[k] = *reinterpret_cast<const float4*>(w + 4 * (lane + 64 * k));
+        bb[k] = *reinterpret_cast<const float4*>(bia + 4 * (lane + 64 * k));
+    }
+    float mean[2], q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) mean[u] = wave_sum_dpp(s[u]) / (float)C;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const float a = v[u][k].x - mean[u], b_ = v[u][k].y - mean[u], c = v[u][k].z - mean[u], d = v[u][k].w - mean[u];
+            q[u] += (a * a + b_ * b_) + (c * c + d * d);
+        }
+    float amax = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float rstd = 1.0f / sqrtf(wave_sum_dpp(q[u]) / (float)C + eps);
+        if (live[u]) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                store_row4<OutT>(yr[u], 4 * (lane + 64 * k), (v[u][k].x - mean[u]) * rstd * ww[k].x + bb[k].x,
+                                 (v[u][k].y - mean[u]) * rstd * ww[k].y + bb[k].y, (v[u][k].z - mean[u]) * rstd * ww[k].z + bb[k].z,
+                                 (v[u][k].w - mean[u]) * rstd * ww[k].w + bb[k].w, amax);
+        }
+    }
+    sat_commit_out<OutT>(sat, amax);
+}
+
 // ------------------------------------------------- depthwise k7 conv + LayerNorm
 // Strip kernel: a workgroup stages S+6 consecutive frames of one utterance in LDS, so every input row crosses
 // the vector-memory path once (plus the 6-row halo) instead of 7 times, and keeps the 7xC taps, the bias and
@@ -656,6 +724,19 @@ extern "C" int swc_layernorm(const float* x, void* y, const float* w, const floa
     const long rows = (long)B * tw;
     if (rows <= 0) return SWC_OK;
     hipStream_t s = (hipStream_t)stream;
+    if ((C == 512 || C == 768) && y_dtype != SWC_FP8) {
+#define LN2_GO(OutT, NV)                                                                                             \
+    hipLaunchKernelGGL((layernorm2_kernel<OutT, NV>), dim3(nblk(rows, 8)), dim3(256), 0, s, x, (OutT*)y, w, b, lens, rows, tw, \
+                       t_in, t_out, eps, swc_sat_counter())
+        if (C == 512) {
+            OUT_DISPATCH3(y_dtype, LN2_GO(float, 2), LN2_GO(bf16_t, 2), LN2_GO(f16s_t, 2));
+        } else {
+            OUT_DISPATCH3(y_dtype, LN2_GO(float, 3), LN2_GO(bf16_t, 3), LN2_GO(f16s_t, 3));
+        }
+#undef LN2_GO
+        SWC_CHECK_LAUNCH("swc_layernorm");
+        return SWC_OK;
+    }
     if (y_dtype == SWC_FP8) {
         hipLaunchKernelGGL(layernorm_kernel<fp8_t>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (fp8_t*)y, w, b, lens, rows,
                            tw, t_in, t_out, C, eps, swc_sat_counter());
