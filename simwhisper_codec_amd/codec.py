@@ -22,6 +22,7 @@ import functools
 import logging
 import math
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -41,6 +42,9 @@ PRECISIONS = {"fp32": ("f32", "f32"), "mixed": ("f16s", "bf16"), "mixed_f32": ("
 _TORCH_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16s": torch.float16}
 
 
+_TLS = threading.local()
+
+
 def _on_model_device(fn):
     """Run a public entry point with the model's GPU as the current device.  Kernels are launched on the current
     device's stream (ops._stream), so a model on cuda:1 called while cuda:0 is current would otherwise enqueue on the
@@ -50,11 +54,18 @@ def _on_model_device(fn):
         dev = self._buffers_device()
         if dev.type != "cuda":  # empty inputs still return empty results (model.py:303-304); anything else raises in _packed()
             return fn(self, *a, **k)
+        active = getattr(_TLS, "active", None)
+        if active is None:
+            active = _TLS.active = set()
+        if id(self) in active:  # an entry point called from another one (encode -> inference_tokenize) on this thread:
+            return fn(self, *a, **k)  # the outer guard is in force (current device, counter pointer are per thread)
         with torch.cuda.device(dev):
             ops.set_saturation_counter(self._sat_state(dev)["buf"])
+            active.add(id(self))
             try:
                 return fn(self, *a, **k)
             finally:
+                active.discard(id(self))
                 ops.set_saturation_counter(None)
     return wrapped
 

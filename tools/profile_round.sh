@@ -9,7 +9,7 @@ mkdir -p $out
 cd "$R"
 python3 bench.py --steps 20 --warmup 5 > $out/bench.json 2> $out/bench.err
 echo "bench done"; tail -c 600 $out/bench.json
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 $R/bench.py --steps 13 --warmup 3 --cpu-baseline off --no-dist > $out/bench_under_rocprof.json 2> $out/rocprof.err )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -o s -- python3 $R/bench.py --steps 13 --warmup 3 --cpu-baseline off --no-dist --no-timer > $out/bench_under_rocprof.json 2> $out/rocprof.err )
 echo "rocprof stats done"
 bash tools/pmc_traffic.sh $out/pmc_traffic > $out/pmc_traffic.log 2>&1
 echo "pmc traffic done"
