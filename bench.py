@@ -52,22 +52,24 @@ class KernelTimer:
         self.rec = []
         self._cur = None
 
-    def begin(self, kind, flops):
+    def begin(self, kind, flops, chip_share=1.0):
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        self._cur = (kind, flops, e0)
+        self._cur = (kind, flops, e0, chip_share)
 
     def end(self):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        kind, flops, e0 = self._cur
-        self.rec.append((kind, flops, e0, e1))
+        kind, flops, e0, share = self._cur
+        self.rec.append((kind, flops, e0, e1, share))
 
     def summary(self):
         out = {}
-        for kind, flops, e0, e1 in self.rec:
+        for kind, flops, e0, e1, share in self.rec:
             d = out.setdefault(kind, {"ms": 0.0, "flops": 0.0, "launches": 0})
-            d["ms"] += e0.elapsed_time(e1)
+            # a launch that shares the chip with a second chain on another stream (two half-batch chains of ConvNeXt
+            # blocks, 125 workgroups each) is charged its share of the duration: the rate stays a whole-chip rate
+            d["ms"] += e0.elapsed_time(e1) * share
             d["flops"] += flops
             d["launches"] += 1
         return out

@@ -65,6 +65,10 @@ const char* swc_last_error(void);
 /* number of visible HIP devices, or SWC_E_NODEV */
 int swc_device_count(void);
 
+/* A one-wave kernel that occupies `stream` for `us` microseconds (<= 100 ms) and exits: phase shift between two chains
+ * of launches on two streams (no reference counterpart; the reference runs one stream). */
+int swc_delay_us(int32_t us, void* stream);
+
 /*
  * Range guard of the reduced-range operand formats.  The reference computes in fp32 and has no such limit
  * (modules.py:214-232 only clamps fp16 / bf16 infinities); here split-f16 activations clip at |x| = 65504 / 64 = 1023

@@ -64,6 +64,7 @@ SIGNATURES = {
     "swc_cast_fp8": [_P, _I, _P, _L, _F, _P],
     "swc_gather_rows": [_P, _P, _P, _L, _I, _P],
     "swc_set_saturation_counter": [_P],
+    "swc_delay_us": [_I, _P],
     "swc_convnext_pack": [_P, _P, _P, _I, _I, _P],
     "swc_convnext_mlp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "swc_convnext_block": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P],

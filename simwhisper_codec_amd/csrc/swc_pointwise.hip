@@ -1037,6 +1037,28 @@ extern "C" int swc_cast_fp8(const void* x, int32_t x_dtype, void* y, int64_t n, 
     return SWC_OK;
 }
 
+// ---------------------------------------------------------------- phase shift between two streams
+// One wave that sleeps for `us` microseconds of the 100 MHz real-time counter and exits (bounded by construction).  Used
+// to start the second of two chains of equal-length launches half a launch late, so that the chains' memory phases fall
+// into each other's compute phases (codec._blocks_two_streams).
+namespace {
+__global__ void delay_kernel(long ticks) {
+    const long t0 = (long)__builtin_amdgcn_s_memrealtime();
+    for (int guard = 0; guard < (1 << 22); ++guard) {  // at most ~4 M sleeps: the loop ends even with a stuck counter
+        if ((long)__builtin_amdgcn_s_memrealtime() - t0 >= ticks) break;
+        __builtin_amdgcn_s_sleep(64);
+    }
+}
+}  // namespace
+
+extern "C" int swc_delay_us(int32_t us, void* stream) {
+    SWC_CHECK_ARG(us >= 0 && us <= 100000, "swc_delay_us: 0 <= us <= 100000");
+    if (us == 0) return SWC_OK;
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long)us * 100);
+    SWC_CHECK_LAUNCH("swc_delay_us");
+    return SWC_OK;
+}
+
 // ---------------------------------------------------------------- code bitstream
 // 8 groups x 11 bits (2016 < 2^11 codes per group) = 88 bits = 11 bytes per 12.5 Hz frame: 1100 bit/s, the
 // codec's nominal bitrate.  Frame t occupies bytes [11 t, 11 t + 11); group g occupies bits [11 g, 11 g + 11) of

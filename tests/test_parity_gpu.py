@@ -298,3 +298,22 @@ def test_cli_end_to_end(tmp_path):
     for k, r in zip(("a.wav", "b.wav"), ref):
         y = load_audio(str(outd / k), 16000).reshape(-1)
         assert (y - r.cpu().clamp(-1, 1)).abs().max().item() <= 1.0 / 32767 + 1e-6
+
+
+def test_vocos_two_stream_chains_are_exact():
+    """vocos_streams = 2 runs the ConvNeXt blocks of the two half-batches as two chains on two streams (out of phase, so
+    that one half's HBM phases fall into the other's compute): every frame's arithmetic is unchanged, the waveforms must
+    be bit-identical to the single-launch-per-block form."""
+    m = model("real", "mixed")
+    g = torch.Generator().manual_seed(5)
+    codes = [torch.randint(0, 2016, (m.num_groups, 120 - (i % 3)), generator=g).to(DEV) for i in range(24)]  # 24 x ~960 frames
+    try:
+        m.vocos_streams = 1
+        one = m.decode(codes)["syn_wav_list"]
+        m.vocos_streams = 2
+        two = m.decode(codes)["syn_wav_list"]
+        two_again = m.decode(codes)["syn_wav_list"]
+    finally:
+        m.vocos_streams = 1
+    for a, b, c in zip(one, two, two_again):
+        assert torch.equal(a, b) and torch.equal(b, c)
