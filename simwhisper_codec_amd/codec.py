@@ -860,24 +860,29 @@ class AudioCodec(nn.Module):
                 wins.append((s0, e0, cl))
         if not wins:
             return None
-        parts = []
+        # Windows are independent rows, so several of them share one tokenize call (rows = windows x utterances) — but
+        # only windows of the same padded length: the encoder of a call runs every row at the longest row's token count,
+        # and the last window of a recording is short (32 x 30 s: 1500-token windows + 500-token tails; batched together
+        # the tails would be computed at 1500 tokens, 50 % more encoder work than the two calls cost)
+        parts = [None] * len(wins)
         per_call = max(1, self.max_rows_per_call // B)
-        for w0 in range(0, len(wins), per_call):
-            grp = wins[w0:w0 + per_call]
-            if len(grp) == 1:
-                s0, e0, cl = grp[0]
-                x, lens = wav[:, None, s0:e0], cl
-            else:  # rows of different windows are independent: one call, rows = windows x utterances
-                wl = max(e0 - s0 for s0, e0, _ in grp)
-                x = torch.zeros(len(grp) * B, 1, wl, device=dev)
-                for k, (s0, e0, _) in enumerate(grp):
-                    x[k * B:(k + 1) * B, 0, : e0 - s0] = wav[:, s0:e0]
-                lens = [v for _, _, cl in grp for v in cl]
-            r = self.inference_tokenize(x, lens)
-            # codes beyond an utterance's length are already zero (FSQ kernel masks them, quantizer.py:193-196);
-            # keeping the first `keep` frames of every window reproduces model.py:291-297 without the copy loop
-            for k in range(len(grp)):
-                parts.append(r["codes"][:, k * B:(k + 1) * B, :keep])
+        by_len = {}
+        for i, wdw in enumerate(wins):
+            by_len.setdefault(wdw[1] - wdw[0], []).append(i)
+        for wl, idx in by_len.items():
+            for w0 in range(0, len(idx), per_call):
+                grp = idx[w0:w0 + per_call]
+                if len(grp) == 1:
+                    s0, e0, cl = wins[grp[0]]
+                    x, lens = wav[:, None, s0:e0], cl
+                else:
+                    x = torch.stack([wav[:, wins[i][0]:wins[i][1]] for i in grp]).view(len(grp) * B, 1, wl)
+                    lens = [v for i in grp for v in wins[i][2]]
+                r = self.inference_tokenize(x, lens)
+                # codes beyond an utterance's length are already zero (FSQ kernel masks them, quantizer.py:193-196);
+                # keeping the first `keep` frames of every window reproduces model.py:291-297 without the copy loop
+                for k, i in enumerate(grp):
+                    parts[i] = r["codes"][:, k * B:(k + 1) * B, :keep]
         return torch.cat(parts, dim=-1) if len(parts) > 1 else parts[0]
 
     @_on_model_device

@@ -19,3 +19,12 @@ SWC_TRACE=time python3 tools/stage_times.py > $out/stage_times.txt 2>&1
 echo "stage times done"; cat $out/stage_times.txt
 python3 tools/bench_pointwise.py > $out/hbm_pointwise.txt 2> $out/hbm_pointwise.err
 echo "pointwise done"
+# other configs of BASELINE.json on the same box (one line each)
+for spec in "--batch 8 --seconds 10" "--batch 32 --seconds 30" "--precision fp32" "--precision bf16" "--precision fp8" "--precision mixed_f32"; do
+  python3 bench.py --steps 6 --warmup 2 --cpu-baseline off --no-dist $spec 2>/dev/null | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.readline()); r=d.get('roofline',{})
+print(json.dumps({'args': '$spec', 'value': d['value'], 'ms_per_step': d['ms_per_step'], 'dominant': r.get('kernel'), 'achieved': r.get('achieved'), 'frac': r.get('frac'), 'other': {k: v['TFLOP/s'] for k, v in r.get('other', {}).items()}}))" >> $out/other_configs.jsonl
+done
+cat $out/other_configs.jsonl
+SWC_TRACE=time python3 tools/stage_times.py 32 30 > $out/stage_times_32x30.txt 2>&1; cat $out/stage_times_32x30.txt
