@@ -114,6 +114,30 @@ def _fold_wn(sd, p):
     return g * v / nrm
 
 
+def length_groups(units, overhead=5000.0, quad=0.11 / 500.0):
+    """Partition rows SORTED BY LENGTH (descending `units`: encoder tokens / decoder tokens per row) into contiguous groups
+    that are each padded to their own longest row.  A call costs about rows x T x (1 + quad x T) token-equivalents (linear
+    layers + attention) plus a fixed `overhead` (launch-bound small kernels, under-filled grids); dynamic programme over
+    the sorted list.  Returns [(start, end)].  A uniform batch is one group."""
+    n = len(units)
+    if n == 0:
+        return []
+    best = [0.0] * (n + 1)
+    cut = [0] * (n + 1)
+    for j in range(1, n + 1):
+        best[j] = float("inf")
+        for i in range(j):
+            t = max(units[i], 1)
+            c = best[i] + (j - i) * t * (1.0 + quad * t) + overhead
+            if c < best[j]:
+                best[j], cut[j] = c, i
+    out, j = [], n
+    while j > 0:
+        out.append((cut[j], j))
+        j = cut[j]
+    return out[::-1]
+
+
 def _config_digest(gp):
     import hashlib
     import json
@@ -652,12 +676,9 @@ class AudioCodec(nn.Module):
         # two-GEMM form, whose 128 x 128 tiles spread over more CUs
         fused = P.fused_mlp and M >= self.fused_mlp_min_rows
         x2 = torch.empty_like(x) if fused else None  # the fused block is not in place: two buffers alternate
-        if fused and self.vocos_streams == 2 and B % 2 == 0 and (B // 2) * Tv >= 64 * 128:
-            # Two half-batches on two streams.  One launch over the whole batch puts all 250 workgroups through their
-            # HBM phases (front half in, residual stream in and out: 131 MB per block) at the same moment with every MFMA
-            # pipe idle; two chains of 125-workgroup launches run out of phase (the second starts one launch late), so one
-            # half's memory phases fall into the other half's compute.  Rows of one utterance stay in one half.
-            x = self._blocks_two_streams(x, x2, B, Tv, C, P)
+        split = self._vocos_split(B, Tv) if fused else None
+        if split is not None:
+            x = self._blocks_two_streams(x, x2, B, Tv, C, P, *split)
         else:
             for blk in P.blocks if fused else ():  # the whole block (depthwise conv + LayerNorm + MLP + residual) is one kernel
                 ops.convnext_block(x, x2, blk["dw"], blk["db"], blk["ln"][0], blk["ln"][1], 1e-6, blk["ws"], blk["b1"],
@@ -676,31 +697,62 @@ class AudioCodec(nn.Module):
         fr = self._mm(sp, P.idft, M, 640, 648, lda=648)
         return ops.istft_ola(fr, P.wsq, B=B, T=Tv)
 
+    length_bucketing = True  # encode() / decode(): rows of similar length share a call (exact; False: one call per batch)
+    bucket_overhead_tokens = 5000.0  # fixed cost of one more call, in row-tokens (length_groups)
+    DECODE_HALO_CODES = 64   # code frames of the batch padding a row's kept samples can depend on (up-sampler +-59)
     vocos_streams = 1  # 1: one launch per ConvNeXt block over the whole batch; 2: two out-of-phase half-batch chains on two
     #                    streams (bit-identical; measured -1.3 % decode time at B = 32 x 10 s, tools/ab_streams.py: opt-in)
     vocos_phase_us = 130  # start of the second half-batch chain after the first (half a block launch)
 
-    def _blocks_two_streams(self, x, x2, B, Tv, C, P):
+    CUS = 256  # one 128-frame workgroup of the fused ConvNeXt kernel per CU and round
+    vocos_split_override = None
+
+    def _vocos_split(self, B, Tv):
+        """(utterances in the first chain, phase shift in us, chip share of a launch) for running the ConvNeXt blocks as two
+        chains on two streams, or None for one launch per block over the whole batch.
+          * grid quantisation: when the last round of 128-frame tiles is poorly filled (32 x 2080 frames = 520 tiles = two
+            full rounds + 8 tiles: 3 rounds of workgroup time for 2.03 rounds of work), the batch is cut in two halves
+            whose chains of launches run beside each other: utterances are independent through the whole backbone, so
+            the chains never wait for each other and the dispatcher always has workgroups of one of them to place
+            (B = 32 x 30 s decode 46.5 -> 41.5 ms; peeling off only the last utterance gave 44.2, tools/ab_split.py);
+          * vocos_streams = 2 (opt-in): two out-of-phase half-batch chains."""
+        if self.vocos_split_override is not None:  # tuning (tools/ab_streams.py): utterances in the first chain, or 0
+            h = int(self.vocos_split_override)
+            return (h, 0, 1.0) if 0 < h < B else None
+        tiles = spec.cdiv(B * Tv, 128)
+        rounds = spec.cdiv(tiles, self.CUS)
+        if rounds >= 2 and tiles < 0.85 * rounds * self.CUS and B >= 2:
+            return B // 2, 0, 0.5
+        if self.vocos_streams == 2 and B % 2 == 0 and (B // 2) * Tv >= 64 * 128:
+            return B // 2, self.vocos_phase_us, 0.5
+        return None
+
+    def _blocks_two_streams(self, x, x2, B, Tv, C, P, h, phase_us, share):
+        """ConvNeXt blocks of utterances [0, h) on the current stream and of [h, B) on a side stream (two independent chains
+        of launches over disjoint rows of the same two residual buffers)."""
         dev = x.device
         st = self.__dict__.get("_side")
         if st is None or st["dev"] != dev:
             st = {"dev": dev, "stream": torch.cuda.Stream(device=dev)}
             self.__dict__["_side"] = st
         side, main = st["stream"], torch.cuda.current_stream(dev)
-        h = B // 2
         xf, x2f = x.view(B * Tv, C), x2.view(B * Tv, C)
-        xa, xb = (xf[: h * Tv], xf[h * Tv:]), (x2f[: h * Tv], x2f[h * Tv:])  # halves of the two buffers; roles swap per block
+        xa, xb = (xf[: h * Tv], xf[h * Tv:]), (x2f[: h * Tv], x2f[h * Tv:])  # parts of the two buffers; roles swap per block
+        nb = (h, B - h)
+        # profiling only: two half-batch chains share the chip evenly; a small side chain runs inside the main chain's time
+        shares = (share, share) if share < 1.0 else (1.0, 0.0)
         side.wait_stream(main)  # the embed / LayerNorm outputs exist
 
-        def run(blk, cur, half):
-            src, dst = (xa[half], xb[half]) if cur == 0 else (xb[half], xa[half])
+        def run(blk, cur, part):
+            src, dst = (xa[part], xb[part]) if cur == 0 else (xb[part], xa[part])
             ops.convnext_block(src, dst, blk["dw"], blk["db"], blk["ln"][0], blk["ln"][1], 1e-6, blk["ws"], blk["b1"],
-                               blk["b2"], blk["g"], B=h, T=Tv, C_=C, I=P.vint, chip_share=0.5)
-        # the second chain starts half a launch late (events only fire at launch boundaries, which would put the chains back
-        # in phase: a one-wave delay kernel shifts it) and stays out of phase from then on: equal launches, in-order streams
+                               blk["b2"], blk["g"], B=nb[part], T=Tv, C_=C, I=P.vint, chip_share=shares[part])
+        # an out-of-phase second chain starts half a launch late (events only fire at launch boundaries, which would put the
+        # chains back in phase: a one-wave delay kernel shifts it) and stays out of phase: equal launches, in-order streams
         cur = 0
         with torch.cuda.stream(side):
-            ops.delay_us(self.vocos_phase_us)
+            if phase_us:
+                ops.delay_us(phase_us)
             for blk in P.blocks:
                 run(blk, cur, 1)
                 cur ^= 1
@@ -830,12 +882,29 @@ class AudioCodec(nn.Module):
             return {"codes_list": []}
         n = [int(w.shape[-1]) if w.dim() else 0 for w in wav_list]
         dev = self._resolve_device(device)
-        wav = self._stack(wav_list, n, dev, torch.float32)
-        allc = self._encode_padded(wav, n, overlap_seconds)
+        # Rows are independent, so the batch is assembled longest utterance first: workgroups are dispatched row by row
+        # (the batch index is the slowest grid dimension of the attention / LayerNorm / snake grids), and with the long
+        # rows first the short ones fill in behind them (longest-processing-time order) instead of leaving the chip to
+        # the last long row.  Results are handed back in the caller's order.
+        order = sorted(range(B), key=lambda i: -n[i])
+        ns = [n[i] for i in order]
         rate = self.encoder_downsample_rate
-        if allc is None:
-            return {"codes_list": [torch.zeros(self.num_groups, 0, device=dev, dtype=torch.long) for _ in range(B)]}
-        return {"codes_list": [allc[:, i, : n[i] // rate] for i in range(B)]}
+        out = [None] * B
+        # Ragged batches: every call runs all its rows at the longest row's token count (as the reference does, at 30 s
+        # always), so rows of similar length are encoded together (length_groups; exact: rows are independent).  Windows
+        # beyond the first of a long recording are full 30 s windows for every row that has them: only the length inside
+        # the first window enters the grouping.
+        chunk = int(self.max_audio_seconds * self.input_sample_rate)
+        groups = (length_groups([spec.token_len(min(v, chunk)) for v in ns], self.bucket_overhead_tokens)
+                  if self.length_bucketing else [(0, B)])
+        for a, b in groups:
+            wav = self._stack([wav_list[i] for i in order[a:b]], ns[a:b], dev, torch.float32)
+            allc = self._encode_padded(wav, ns[a:b], overlap_seconds)
+            for k in range(a, b):
+                i = order[k]
+                out[i] = (torch.zeros(self.num_groups, 0, device=dev, dtype=torch.long) if allc is None
+                          else allc[:, k - a, : n[i] // rate])
+        return {"codes_list": out}
 
     @_on_model_device
     @torch.inference_mode()
@@ -896,11 +965,14 @@ class AudioCodec(nn.Module):
         B = len(codes_list)
         if B == 0:
             return {"syn_wav_list": []}
-        n = [int(c.shape[-1]) for c in codes_list]
-        L = max(max(n), int(pad_to_length or 0))
+        n_in = [int(c.shape[-1]) for c in codes_list]
+        L = max(max(n_in), int(pad_to_length or 0))
         dev = self._resolve_device(device)
         if L == 0:
             return {"syn_wav_list": [torch.zeros(0, device=dev) for _ in range(B)]}
+        order = sorted(range(B), key=lambda i: -n_in[i])  # longest first, as in encode(); rows are independent
+        codes_list = [codes_list[i] for i in order]
+        n = [n_in[i] for i in order]
         G = self.num_groups
         dt0 = codes_list[0].dtype
         if (dev.type == "cuda" and dt0 in (torch.int32, torch.int64) and B * G <= 65535
@@ -919,8 +991,21 @@ class AudioCodec(nn.Module):
             codes = torch.zeros(self.num_groups, B, L, device=dev, dtype=torch.long)
             for i, c in enumerate(codes_list):
                 codes[:, i, : n[i]] = c.to(dev)
-        wav = self._decode_padded(codes, n, overlap_seconds)
-        return {"syn_wav_list": [wav[i, : n[i] * self.decoder_upsample_rate] for i in range(B)]}
+        # Ragged batches.  The reference pads every row to the batch maximum and its un-masked up-sampler / Vocos read that
+        # padding — but only within their receptive fields: the up-sampler reaches +-59 code frames, the decoder
+        # transformer is masked by length and its output is zeroed beyond it, Vocos + ISTFT reach +-10 code frames.  A row
+        # decoded at min(L, n_i + 64) code frames therefore gives bit-identical samples below n_i * 1280, and rows of
+        # similar length share a call (length_groups) instead of all running at the longest row's length.
+        up = self.decoder_upsample_rate
+        out = [None] * B
+        need = [min(L, v + self.DECODE_HALO_CODES) for v in n]
+        groups = length_groups([4 * v for v in need], self.bucket_overhead_tokens) if self.length_bucketing else [(0, B)]
+        for a, b in groups:
+            Lg = L if not self.length_bucketing else max(need[a:b])
+            wav = self._decode_padded(codes[:, a:b, :Lg], n[a:b], overlap_seconds)
+            for k in range(a, b):
+                out[order[k]] = wav[k - a, : n[k] * up]
+        return {"syn_wav_list": out}
 
     @_on_model_device
     @torch.inference_mode()

@@ -211,3 +211,18 @@ def test_packed_operand_file_roundtrip(tmp_path):
     from safetensors.torch import save_file
     save_file({"a": torch.zeros(2)}, str(tmp_path / "plain.safetensors"))
     assert packed.peek(str(tmp_path / "plain.safetensors")) is None
+
+
+def test_length_groups_partition():
+    from simwhisper_codec_amd.codec import length_groups
+    assert length_groups([]) == [] and length_groups([7]) == [(0, 1)]
+    assert length_groups([500] * 32) == [(0, 32)]                      # a uniform batch stays one call
+    g = length_groups([1500, 1500, 20, 20, 20])
+    assert g == [(0, 2), (2, 5)]
+    import random
+    random.seed(1)
+    u = sorted((random.randint(10, 1500) for _ in range(100)), reverse=True)
+    g = length_groups(u)
+    assert g[0][0] == 0 and g[-1][1] == 100 and all(g[i][1] == g[i + 1][0] for i in range(len(g) - 1))
+    padded = sum((b - a) * u[a] for a, b in g)
+    assert sum(u) <= padded < 100 * u[0] and 1 < len(g) < 20

@@ -317,3 +317,45 @@ def test_vocos_two_stream_chains_are_exact():
         m.vocos_streams = 1
     for a, b, c in zip(one, two, two_again):
         assert torch.equal(a, b) and torch.equal(b, c)
+
+
+@pytest.mark.parametrize("tag,precision", [("tiny", "fp32"), ("real", "mixed")])
+def test_length_bucketing_is_exact(tag, precision):
+    """Ragged batches: encode() / decode() run rows of similar length together (length_groups) instead of every row at the
+    longest row's length; decode rows see min(L, n_i + 64) code frames of the batch padding (the receptive field of the
+    reference's un-masked up-sampler is +-59).  Codes and every kept sample must be bit-identical to the one-call form,
+    and the codes equal the oracle's."""
+    from simwhisper_codec_amd import synth
+    from simwhisper_codec_amd.codec import length_groups
+    m = model(tag, precision)
+    secs = ([27.3, 1.1, 9.0, 22.5, 0.05, 3.3, 12.7, 2.0, 30.0, 41.0] if tag == "tiny" else
+            [21.5, 20.2, 22.3, 19.1, 18.4, 21.0, 23.9, 20.7] + [1.1, 2.0, 0.5, 3.3, 1.7, 2.4, 0.9, 1.3] * 2)
+    wavs = [synth.synth_audio(int(16000 * t) + 13 * i, index=950 + i, kind="speech" if i % 2 else "noise").to(DEV)
+            for i, t in enumerate(secs)]
+    assert len(length_groups(sorted([int(16000 * t) // 320 for t in secs], reverse=True))) > 1  # the case is really ragged
+    keep_rows = m.fused_mlp_min_rows
+    try:
+        # the same kernels on both sides (the fused ConvNeXt kernel is chosen by the number of Vocos frames of a call and
+        # rounds its bf16 intermediate in another order than the two-GEMM form): bit-identical
+        m.fused_mlp_min_rows = 1 << 40
+        m.length_bucketing = False
+        c0 = m.encode(wavs)["codes_list"]
+        w0 = m.decode(c0)["syn_wav_list"]
+        m.length_bucketing = True
+        c1 = m.encode(wavs)["codes_list"]
+        w1 = m.decode(c1)["syn_wav_list"]
+        # default kernel choice: codes identical, waveforms within the bf16 decode tolerance
+        m.fused_mlp_min_rows = keep_rows
+        w2 = m.decode(c1)["syn_wav_list"]
+    finally:
+        m.length_bucketing = True
+        m.fused_mlp_min_rows = keep_rows
+    for a, b in zip(c0 + w0, c1 + w1):
+        assert a.shape == b.shape and torch.equal(a, b)
+    for a, b in zip(w1, w2):
+        if a.numel():
+            assert _relerr(b.cpu().numpy(), a.cpu().numpy()) < (TOL_FP32 if precision == "fp32" else TOL_BF16)
+    if tag == "tiny":
+        want = oracle(tag).encode([w.cpu() for w in wavs], trim=True)["codes_list"]
+        for a, b in zip(c1, want):
+            assert torch.equal(a.cpu().long(), b.long())
