@@ -146,10 +146,18 @@ class _StdoutToStderr:
 
 
 def git_commit():
+    """HEAD of the checkout, or (on a GPU box: snapshot without .git) the commit stamped beside the library at build time."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE,
-                              stderr=subprocess.DEVNULL, text=True, timeout=5).stdout.strip() or None
+        c = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, text=True, timeout=5).stdout.strip()
+        if c:
+            return c
     except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, "simwhisper_codec_amd", "_build_commit.txt")) as f:
+            return f.read().strip() or None
+    except OSError:
         return None
 
 

@@ -67,7 +67,23 @@ def build_library(force=False, verbose=False):
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     os.replace(tmp, LIB_PATH)
+    stamp_commit()
     return LIB_PATH
+
+
+def stamp_commit():
+    """The GPU box receives a snapshot without .git: leave the commit the library was built from next to it, so that
+    bench.py / profile summaries taken there can name it (the file is git-ignored and travels with the .so)."""
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                           text=True, timeout=5)
+        dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], stdout=subprocess.PIPE,
+                               stderr=subprocess.DEVNULL, text=True, timeout=5).stdout.strip()
+        if r.returncode == 0 and r.stdout.strip():
+            with open(os.path.join(HERE, "_build_commit.txt"), "w") as f:
+                f.write(r.stdout.strip() + ("+dirty" if dirty else "") + "\n")
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":
