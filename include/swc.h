@@ -135,9 +135,12 @@ int swc_attention(const void* qkv, void* out, const int32_t* lens, int32_t B, in
  * dtype F16S = split-f16 q/k/v in (SWC_F16S_ACT_SCALE), split-f16 out, three f16 MFMAs per product
  * (f32-class scores and outputs).  128 queries per workgroup, K/V tiles double-buffered by LDS-DMA,
  * V^T operand through ds_read_b64_tr_b16.
+ * row_start (NULL = padded layout, utterance b at rows b*T ..): VALID-TOKEN PACKING — utterance b's lens[b] rows of qkv and
+ * out start at row row_start[b] and nothing follows them but the next utterance: ragged batches then cost their valid
+ * tokens, not B x the longest row (the reference pads every row, modules.py:111-143 masks afterwards).
  */
 int swc_attention16(const void* qkv, void* out, const int32_t* lens, int32_t B, int32_t T, int32_t H,
-                    int32_t dtype, void* stream);
+                    int32_t dtype, const int32_t* row_start, void* stream);
 /* f32 qkv in and the output written as out_dtype (F32 | F16S at SWC_F16S_ACT_SCALE), exact-f32 MFMA */
 int swc_attention_ex(const void* qkv, void* out, const int32_t* lens, int32_t B, int32_t T, int32_t H,
                      int32_t out_dtype, void* stream);
@@ -151,7 +154,13 @@ int swc_attention_ex(const void* qkv, void* out, const int32_t* lens, int32_t B,
  */
 int swc_layernorm(const float* x, void* y, const float* w, const float* b, const int32_t* lens,
                   int32_t B, int32_t t_in, int32_t t_out, int32_t C, float eps, int32_t y_dtype,
-                  void* stream);
+                  const int32_t* row_start, void* stream);
+/* row_start != NULL (needs lens): x is PACKED — utterance b's lens[b] rows start at row row_start[b]; y stays padded
+ * [B][t_out][C] (this is how the packed token stream of a transformer returns to the padded layout of the convolutions). */
+
+/* padded [B][T][row_bytes] -> packed: the first lens[b] rows of utterance b are copied to row row_start[b] of dst. */
+int swc_pack_rows(const void* src, void* dst, const int32_t* row_start, const int32_t* lens, int32_t B, int32_t T,
+                  int64_t row_bytes, void* stream);
 
 /*
  * ConvNeXt back half in one kernel (modules.py:1241-1247, 24x per Vocos call = half of all FLOPs of the path):

@@ -44,8 +44,8 @@ SIGNATURES = {
     "swc_gemm": [C.POINTER(GemmArgs), _P],
     "swc_attention": [_P, _P, _P, _I, _I, _I, _I, _P],
     "swc_attention_ex": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "swc_attention16": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "swc_layernorm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
+    "swc_attention16": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "swc_layernorm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P, _P],
     "swc_dwconv7_ln": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P],
     "swc_snake_aa": [_P, _P, _P, _P, C.POINTER(_F), _I, _I, _I, _I, _P],
     "swc_fsq_encode": [_P, _L, _P, _P, _P, C.POINTER(_F), _I, _I, _I, _I, _P],
@@ -65,6 +65,7 @@ SIGNATURES = {
     "swc_gather_rows": [_P, _P, _P, _L, _I, _P],
     "swc_set_saturation_counter": [_P],
     "swc_delay_us": [_I, _P],
+    "swc_pack_rows": [_P, _P, _P, _P, _I, _I, _L, _P],
     "swc_convnext_pack": [_P, _P, _P, _I, _I, _P],
     "swc_convnext_mlp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "swc_convnext_block": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P],

@@ -523,24 +523,44 @@ class AudioCodec(nn.Module):
             kw["out_scale"] = ops.FP8_ACT_SCALE
         return ops.gemm(A, pw.w, M, N, K, alpha=pw.alpha, out_dtype=out_dtype, **kw)
 
-    def _transformer(self, h, lens, B, T, layers, H, dt):
-        """12 x OmniWhisperTransformerLayer (modules.py:214-232). h: [B*T, D] f32 residual stream (updated in place)."""
+    def _transformer(self, h, lens, B, T, layers, H, dt, row_start=None):
+        """12 x OmniWhisperTransformerLayer (modules.py:214-232). h: f32 residual stream (updated in place), padded
+        [B*T, D] or — row_start given — packed [sum(len), D] (every row-wise kernel just sees fewer rows; attention finds
+        utterance b at row_start[b])."""
         D = h.shape[-1]
-        M = B * T
+        M = h.shape[0]
         fp8 = dt == ops.FP8_T
         adt = torch.bfloat16 if fp8 else dt  # fp8 linears feed a bf16 attention
+        lnB, lnT = (B, T) if row_start is None else (1, M)
         for L in layers:
-            x = ops.layernorm(h, L.ln1[0], L.ln1[1], 1e-5, B=B, t_in=T, C_=D, out_dtype=dt)
+            x = ops.layernorm(h, L.ln1[0], L.ln1[1], 1e-5, B=lnB, t_in=lnT, C_=D, out_dtype=dt)
             qkv = self._mm(x, L.wqkv, M, 3 * D, D, lda=D, bias=L.bqkv, out_dtype=adt)
-            a = ops.attention(qkv, lens, B, T, H)
+            a = ops.attention(qkv, lens, B, T, H, row_start=row_start, rows=M)
             if fp8:
                 a = ops.cast_fp8(a)
             self._mm(a, L.wo, M, D, D, lda=D, bias=L.bo, residual=h, out=h)
-            x = ops.layernorm(h, L.ln2[0], L.ln2[1], 1e-5, B=B, t_in=T, C_=D, out_dtype=dt)
+            x = ops.layernorm(h, L.ln2[0], L.ln2[1], 1e-5, B=lnB, t_in=lnT, C_=D, out_dtype=dt)
             F_ = L.b1.shape[0]
             f = self._mm(x, L.w1, M, F_, D, lda=D, bias=L.b1, act=ops.ACT_GELU, out_dtype=dt)
             self._mm(f, L.w2, M, D, F_, lda=F_, bias=L.b2, residual=h, out=h)
         return h
+
+    varlen_packing = True   # ragged calls: the transformers run on the valid tokens only (packed rows), not on B x longest
+    PACK_BELOW = 0.9        # ... when the valid tokens are under this fraction of the padded rows
+
+    def _pack_plan(self, lens_host, T, dt, dev):
+        """(row_start device tensor, total rows) when the transformer of this call should run packed, else (None, B*T).
+        Packing is exact (rows are independent; attention reads an utterance's own rows only) and exists for the 16-bit
+        operand attention kernel (split-f16 / bf16 / fp8 presets)."""
+        B = len(lens_host)
+        total = sum(lens_host)
+        if (not self.varlen_packing or dt == torch.float32 or total == 0 or total >= self.PACK_BELOW * B * T):
+            return None, B * T
+        cu, acc = [], 0
+        for v in lens_host:
+            cu.append(acc)
+            acc += v
+        return self._dev_ints(cu, dev), total
 
     def _res_units(self, h, units, B, T, C, dt):
         """3 x ResidualUnit (modules.py:37-49). h: [B*T, C] f32, updated in place."""
@@ -587,14 +607,20 @@ class AudioCodec(nn.Module):
         c1 = self._mm(mel, P.c1w, B * Tm, D, P.n_mel, lda=P.n_mel, ldw=3 * P.n_mel, bias=P.c1b, taps=3, pad=1, t_in=Tm,
                       t_out=Tm, out_dtype=dt)
         h = self._mm(c1, P.c2w, B * Ttok, D, D, lda=D, ldw=3 * D, bias=P.c2b, taps=3, stride=2, pad=1, t_in=Tm, t_out=Ttok)
-        lens = self._dev_ints(tok_host, dev)
-        self._transformer(h, lens, B, Ttok, P.enc_layers, P.He, P.enc_ldt)
+        tok_c = [min(t, Ttok) for t in tok_host]
+        lens = self._dev_ints(tok_c, dev)
+        row_start, total = self._pack_plan(tok_c, Ttok, P.enc_ldt, dev)
+        if row_start is not None:  # ragged call: the 12 layers see the valid tokens only
+            h = ops.pack_rows(h, row_start, lens, B=B, T=Ttok, total=total)
+        self._transformer(h, lens, B, Ttok, P.enc_layers, P.He, P.enc_ldt, row_start=row_start)
         s = P.stack
         tds_full = spec.cdiv(t_full, s)
         Tds = min(tds_full, spec.cdiv(Ttok, s) + 64)
         # encoder output is exactly zero beyond each length: the LayerNorm kernel writes those rows as zeros
-        # (zero halves are a zero in split-f16 too), so no separate fill pass is needed
-        hn = ops.layernorm(h, P.enc_ln[0], P.enc_ln[1], 1e-5, B=B, t_in=Ttok, t_out=Tds * s, C_=D, lens=lens, out_dtype=dt)
+        # (zero halves are a zero in split-f16 too), so no separate fill pass is needed; a packed stream returns to
+        # the padded layout here
+        hn = ops.layernorm(h, P.enc_ln[0], P.enc_ln[1], 1e-5, B=B, t_in=Ttok, t_out=Tds * s, C_=D, lens=lens, out_dtype=dt,
+                           row_start=row_start)
         return hn, Tds
 
     def _downsample(self, hn, B, Tds, P):
@@ -641,9 +667,14 @@ class AudioCodec(nn.Module):
         """OmniAudioDecoder (modules.py:437-474): 12 layers (masked), LayerNorm + mask, deconv1 (k3, s2), deconv2 (k3),
         crop to 2*Tt.  x [B*Tt, D] f32 (updated in place).  Returns mel [B, 2*Tt, 80] in the decode operand format."""
         dt, dev, D = P.ddt, x.device, P.Dd
-        lens = self._dev_ints([l * P.stack for l in lat_host], dev)
-        self._transformer(x, lens, B, Tt, P.dec_layers, P.Hd, dt)
-        hn = ops.layernorm(x, P.dec_ln[0], P.dec_ln[1], 1e-5, B=B, t_in=Tt, C_=D, lens=lens, out_dtype=dt)
+        lens_h = [min(l * P.stack, Tt) for l in lat_host]
+        lens = self._dev_ints(lens_h, dev)
+        row_start, total = self._pack_plan(lens_h, Tt, dt, dev)
+        if row_start is not None:  # tokens beyond a length are masked keys and zeroed outputs: they need not exist
+            x = ops.pack_rows(x, row_start, lens, B=B, T=Tt, total=total)
+        self._transformer(x, lens, B, Tt, P.dec_layers, P.Hd, dt, row_start=row_start)
+        hn = ops.layernorm(x, P.dec_ln[0], P.dec_ln[1], 1e-5, B=B, t_in=Tt, C_=D, lens=lens, out_dtype=dt,
+                           row_start=row_start)
         y3 = self._mm(hn, P.d1w, B * Tt, 3 * D, D, lda=D)
         Tv = 2 * Tt
         d1 = ops.deconv_col2im(y3, P.d1b, B=B, T=Tt, C_=D, s=2, t_out=Tv + 1, out_dtype=dt)
@@ -895,8 +926,11 @@ class AudioCodec(nn.Module):
         # beyond the first of a long recording are full 30 s windows for every row that has them: only the length inside
         # the first window enters the grouping.
         chunk = int(self.max_audio_seconds * self.input_sample_rate)
+        # (with valid-token packing the 12 layers of a ragged call cost their valid tokens anyway, and what stays padded —
+        # log-mel, conv stem, down-sampler — is 5 % of the encoder: one call then beats several)
+        packs = self.varlen_packing and PRECISIONS[self._precision][0] != "f32"
         groups = (length_groups([spec.token_len(min(v, chunk)) for v in ns], self.bucket_overhead_tokens)
-                  if self.length_bucketing else [(0, B)])
+                  if self.length_bucketing and not packs else [(0, B)])
         for a, b in groups:
             wav = self._stack([wav_list[i] for i in order[a:b]], ns[a:b], dev, torch.float32)
             allc = self._encode_padded(wav, ns[a:b], overlap_seconds)
@@ -935,17 +969,27 @@ class AudioCodec(nn.Module):
         # the tails would be computed at 1500 tokens, 50 % more encoder work than the two calls cost)
         parts = [None] * len(wins)
         per_call = max(1, self.max_rows_per_call // B)
+        # ... unless the transformer of the call runs on packed valid tokens anyway (varlen_packing): then all windows go
+        # together again (one call of 64 000 valid tokens instead of 48 000 + 16 000) and only log-mel / conv stem /
+        # down-sampler (5 % of the encoder) see the padding
+        packs = self.varlen_packing and PRECISIONS[self._precision][0] != "f32"
         by_len = {}
         for i, wdw in enumerate(wins):
-            by_len.setdefault(wdw[1] - wdw[0], []).append(i)
-        for wl, idx in by_len.items():
+            by_len.setdefault(0 if packs else wdw[1] - wdw[0], []).append(i)
+        for _, idx in by_len.items():
             for w0 in range(0, len(idx), per_call):
                 grp = idx[w0:w0 + per_call]
+                wl = max(wins[i][1] - wins[i][0] for i in grp)
                 if len(grp) == 1:
                     s0, e0, cl = wins[grp[0]]
                     x, lens = wav[:, None, s0:e0], cl
                 else:
-                    x = torch.stack([wav[:, wins[i][0]:wins[i][1]] for i in grp]).view(len(grp) * B, 1, wl)
+                    if all(wins[i][1] - wins[i][0] == wl for i in grp):
+                        x = torch.stack([wav[:, wins[i][0]:wins[i][1]] for i in grp]).view(len(grp) * B, 1, wl)
+                    else:
+                        x = torch.zeros(len(grp) * B, 1, wl, device=dev)
+                        for k, i in enumerate(grp):
+                            x[k * B:(k + 1) * B, 0, : wins[i][1] - wins[i][0]] = wav[:, wins[i][0]:wins[i][1]]
                     lens = [v for i in grp for v in wins[i][2]]
                 r = self.inference_tokenize(x, lens)
                 # codes beyond an utterance's length are already zero (FSQ kernel masks them, quantizer.py:193-196);
@@ -999,9 +1043,14 @@ class AudioCodec(nn.Module):
         up = self.decoder_upsample_rate
         out = [None] * B
         need = [min(L, v + self.DECODE_HALO_CODES) for v in n]
-        groups = length_groups([4 * v for v in need], self.bucket_overhead_tokens) if self.length_bucketing else [(0, B)]
+        # (measured, tools/bench_ragged.py: once the decoder transformer runs packed, one call beats the grouped calls —
+        # what stays padded, up-sampler and Vocos, loses more to small calls than it saves; presets without the packed
+        # attention kernel keep the grouping)
+        packs = self.varlen_packing and PRECISIONS[self._precision][1] != "f32"
+        bucket = self.length_bucketing and not packs
+        groups = length_groups([4 * v for v in need], self.bucket_overhead_tokens) if bucket else [(0, B)]
         for a, b in groups:
-            Lg = L if not self.length_bucketing else max(need[a:b])
+            Lg = L if not bucket else max(need[a:b])
             wav = self._decode_padded(codes[:, a:b, :Lg], n[a:b], overlap_seconds)
             for k in range(a, b):
                 out[order[k]] = wav[k - a, : n[k] * up]

@@ -47,7 +47,8 @@ constexpr int KT16 = 64;   // keys per tile
 
 template <int PLANES>
 __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__ qkv, unsigned short* __restrict__ out,
-                                                        const int* __restrict__ lens, int T, int H) {
+                                                        const int* __restrict__ lens, int T, int H,
+                                                        const int* __restrict__ row_start) {
     constexpr int ROWB = 128 * PLANES;    // bytes of one (token, head) row: 64 bf16, or [32 hi|32 lo|32 hi|32 lo] f16
     constexpr int CPR = ROWB / 16;        // 16-byte chunks per row
     constexpr int TILE = KT16 * ROWB;     // bytes of a K or V tile
@@ -62,21 +63,26 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
     const long part = (long)D * 2 * PLANES;  // byte offset between the q, k and v parts
     int len = lens[b];
     len = len < 0 ? 0 : (len > T ? T : len);
-    const char* base = qkv + (long)b * T * ldb + (long)head * ROWB;
+    // padded layout: utterance b owns rows b * T .. b * T + T - 1; packed (row_start != NULL): rows row_start[b] ..
+    // row_start[b] + len - 1 and nothing else — rows beyond its length belong to the next utterance and are neither read
+    // nor written
+    const long r0 = row_start ? (long)row_start[b] : (long)b * T;
+    const int qlim = row_start ? len : T;
+    const char* base = qkv + r0 * ldb + (long)head * ROWB;
 
     auto krow_swz = [](int row) { return PLANES == 1 ? (((row >> 1) ^ ((row >> 4) << 1)) & 7) : (row & 15); };
     auto vrow_swz = [](int row) { return PLANES == 1 ? ((row >> 1) & 3) : (row & 7); };
 
     // ---- output addressing
     auto store_o = [&](int q, int d, float a, float bq, float c, float e) {
-        if (q >= T) return;
+        if (q >= qlim) return;
         if constexpr (PLANES == 1) {
             uint2 u;
             u.x = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(bq) << 16);
             u.y = (unsigned)f32_to_bf16(c) | ((unsigned)f32_to_bf16(e) << 16);
-            *reinterpret_cast<uint2*>(out + ((long)b * T + q) * D + head * 64 + d) = u;
+            *reinterpret_cast<uint2*>(out + (r0 + q) * D + head * 64 + d) = u;
         } else {
-            f16s_store4(out + ((long)b * T + q) * 2L * D, head * 64 + d, a, bq, c, e);
+            f16s_store4(out + (r0 + q) * 2L * D, head * 64 + d, a, bq, c, e);
         }
     };
 
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         int q = q0 + wave * 32 + qt * 16 + fr;
-        q = q < T ? q : T - 1;
+        q = q < qlim ? q : qlim - 1;
         const char* qp = base + (long)q * ldb;
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -298,12 +304,12 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
 }
 
 template <int PLANES>
-int launch16(const void* qkv, void* out, const int32_t* lens, int B, int T, int H, hipStream_t s) {
+int launch16(const void* qkv, void* out, const int32_t* lens, int B, int T, int H, const int32_t* row_start, hipStream_t s) {
     constexpr int LDS = 2 * 2 * KT16 * 128 * PLANES;
     auto kern = attn16_kernel<PLANES>;
     if (LDS > 48 * 1024) SWC_ENABLE_LDS(kern, LDS, "swc_attention16");
     dim3 grid((T + QB16 - 1) / QB16, H, B), block(256);
-    hipLaunchKernelGGL(kern, grid, block, LDS, s, (const char*)qkv, (unsigned short*)out, lens, T, H);
+    hipLaunchKernelGGL(kern, grid, block, LDS, s, (const char*)qkv, (unsigned short*)out, lens, T, H, row_start);
     return SWC_OK;
 }
 
@@ -311,14 +317,14 @@ int launch16(const void* qkv, void* out, const int32_t* lens, int B, int T, int 
 
 // dtype: SWC_BF16 (bf16 in, bf16 out) or SWC_F16S (split-f16 in at scale 64, split-f16 out at scale 64)
 extern "C" int swc_attention16(const void* qkv, void* out, const int32_t* lens, int32_t B, int32_t T, int32_t H,
-                               int32_t dtype, void* stream) {
+                               int32_t dtype, const int32_t* row_start, void* stream) {
     SWC_CHECK_ARG(qkv && out && lens, "swc_attention16: null pointer");
     SWC_CHECK_ARG(B >= 0 && T >= 0 && H > 0 && B <= 65535 && H <= 65535, "swc_attention16: bad B/T/H");
     SWC_CHECK_ARG(dtype == SWC_BF16 || dtype == SWC_F16S, "swc_attention16: dtype must be BF16 or F16S");
     SWC_CHECK_ARG(aligned16(qkv) && aligned16(out), "swc_attention16: unaligned");
     if (B == 0 || T == 0) return SWC_OK;
-    int rc = dtype == SWC_BF16 ? launch16<1>(qkv, out, lens, B, T, H, (hipStream_t)stream)
-                               : launch16<2>(qkv, out, lens, B, T, H, (hipStream_t)stream);
+    int rc = dtype == SWC_BF16 ? launch16<1>(qkv, out, lens, B, T, H, row_start, (hipStream_t)stream)
+                               : launch16<2>(qkv, out, lens, B, T, H, row_start, (hipStream_t)stream);
     if (rc != SWC_OK) return rc;
     SWC_CHECK_LAUNCH("swc_attention16");
     return SWC_OK;

@@ -51,12 +51,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bia,
                                                         const int* __restrict__ lens, long rows, int tw,
-                                                        int t_in, int t_out, int C, float eps, unsigned* sat) {
+                                                        int t_in, int t_out, int C, float eps, unsigned* sat,
+                                                        const int* __restrict__ row_start) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int b = (int)(r / tw), t = (int)(r - (long)b * tw);
-    const float* xr = x + ((long)b * t_in + t) * C;
+    const float* xr = x + ((row_start ? (long)row_start[b] : (long)b * t_in) + t) * C;
     OutT* yr = y + ((long)b * t_out + t) * row_units<OutT>(C);
     const int nv = C >> 2;  // float4 count
     if (t >= t_in || (lens && t >= lens[b])) {  // masked rows, and the zero extension beyond the input (t_out > t_in)
@@ -106,7 +107,8 @@ template <typename OutT, int NV>
 __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict__ x, OutT* __restrict__ y,
                                                          const float* __restrict__ w, const float* __restrict__ bia,
                                                          const int* __restrict__ lens, long rows, int tw, int t_in,
-                                                         int t_out, float eps, unsigned* sat) {
+                                                         int t_out, float eps, unsigned* sat,
+                                                         const int* __restrict__ row_start) {
     constexpr int C = 256 * NV;
     const int lane = threadIdx.x & 63;
     const long r0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
@@ -119,9 +121,10 @@ __global__ __launch_bounds__(256) void layernorm2_kernel(const float* __restrict
         const long r = r0 + u;
         const bool in = r < rows;
         const int b = in ? (int)(r / tw) : 0, t = in ? (int)(r - (long)b * tw) : 0;
-        xr[u] = x + ((long)b * t_in + t) * C;
-        yr[u] = y + ((long)b * t_out + t) * row_units<OutT>(C);
         live[u] = in && t < t_in && !(lens && t >= lens[b]);
+        // packed input (row_start != NULL): utterance b's rows start at row_start[b]; only live rows are dereferenced
+        xr[u] = x + ((row_start && in ? (long)row_start[b] : (long)b * t_in) + t) * C;
+        yr[u] = y + ((long)b * t_out + t) * row_units<OutT>(C);
         if (in && !live[u]) {  // masked rows and the zero extension beyond the input
             float z_ = 0.f;
 #pragma unroll
@@ -714,8 +717,9 @@ inline unsigned nblk(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 extern "C" int swc_layernorm(const float* x, void* y, const float* w, const float* b, const int32_t* lens,
                              int32_t B, int32_t t_in, int32_t t_out, int32_t C, float eps, int32_t y_dtype,
-                             void* stream) {
+                             const int32_t* row_start, void* stream) {
     SWC_CHECK_ARG(x && y && w && b, "swc_layernorm: null pointer");
+    SWC_CHECK_ARG(!row_start || lens, "swc_layernorm: packed input (row_start) needs lens");
     SWC_CHECK_ARG(C > 0 && C % 4 == 0 && C <= 256 * LN_MAXV, "swc_layernorm: C=%d unsupported", C);
     SWC_CHECK_ARG(y_dtype == SWC_F32 || y_dtype == SWC_BF16 || y_dtype == SWC_F16S || y_dtype == SWC_FP8,
                   "swc_layernorm: bad dtype");
@@ -727,7 +731,7 @@ extern "C" int swc_layernorm(const float* x, void* y, const float* w, const floa
     if ((C == 512 || C == 768) && y_dtype != SWC_FP8) {
 #define LN2_GO(OutT, NV)                                                                                             \
     hipLaunchKernelGGL((layernorm2_kernel<OutT, NV>), dim3(nblk(rows, 8)), dim3(256), 0, s, x, (OutT*)y, w, b, lens, rows, tw, \
-                       t_in, t_out, eps, swc_sat_counter())
+                       t_in, t_out, eps, swc_sat_counter(), row_start)
         if (C == 512) {
             OUT_DISPATCH3(y_dtype, LN2_GO(float, 2), LN2_GO(bf16_t, 2), LN2_GO(f16s_t, 2));
         } else {
@@ -739,17 +743,17 @@ extern "C" int swc_layernorm(const float* x, void* y, const float* w, const floa
     }
     if (y_dtype == SWC_FP8) {
         hipLaunchKernelGGL(layernorm_kernel<fp8_t>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (fp8_t*)y, w, b, lens, rows,
-                           tw, t_in, t_out, C, eps, swc_sat_counter());
+                           tw, t_in, t_out, C, eps, swc_sat_counter(), row_start);
         SWC_CHECK_LAUNCH("swc_layernorm");
         return SWC_OK;
     }
     OUT_DISPATCH3(y_dtype,
                   hipLaunchKernelGGL(layernorm_kernel<float>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (float*)y, w,
-                                     b, lens, rows, tw, t_in, t_out, C, eps, swc_sat_counter()),
+                                     b, lens, rows, tw, t_in, t_out, C, eps, swc_sat_counter(), row_start),
                   hipLaunchKernelGGL(layernorm_kernel<bf16_t>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (bf16_t*)y,
-                                     w, b, lens, rows, tw, t_in, t_out, C, eps, swc_sat_counter()),
+                                     w, b, lens, rows, tw, t_in, t_out, C, eps, swc_sat_counter(), row_start),
                   hipLaunchKernelGGL(layernorm_kernel<f16s_t>, dim3(nblk(rows, 4)), dim3(256), 0, s, x, (f16s_t*)y,
-                                     w, b, lens, rows, tw, t_in, t_out, C, eps, swc_sat_counter()));
+                                     w, b, lens, rows, tw, t_in, t_out, C, eps, swc_sat_counter(), row_start));
     SWC_CHECK_LAUNCH("swc_layernorm");
     return SWC_OK;
 }
@@ -1034,6 +1038,34 @@ extern "C" int swc_cast_fp8(const void* x, int32_t x_dtype, void* y, int64_t n, 
         hipLaunchKernelGGL(cast_fp8_kernel<bf16_t>, dim3(nblk(n4, 256)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)x, (unsigned*)y, n4, scale, swc_sat_counter());
     SWC_CHECK_LAUNCH("swc_cast_fp8");
+    return SWC_OK;
+}
+
+// ---------------------------------------------------------------- valid-token packing
+// [B][T][row_bytes] padded rows -> packed rows: utterance b's first lens[b] rows land at row_start[b] (16-byte chunks).
+namespace {
+__global__ void pack_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const int* __restrict__ row_start,
+                                 const int* __restrict__ lens, int T, int chunks) {
+    const int b = blockIdx.y;
+    const int n = lens[b] < T ? lens[b] : T;
+    const long total = (long)n * chunks;
+    const uint4* s = src + (long)b * T * chunks;
+    uint4* d = dst + (long)row_start[b] * chunks;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) d[i] = s[i];
+}
+}  // namespace
+
+extern "C" int swc_pack_rows(const void* src, void* dst, const int32_t* row_start, const int32_t* lens, int32_t B, int32_t T,
+                             int64_t row_bytes, void* stream) {
+    SWC_CHECK_ARG(src && dst && row_start && lens, "swc_pack_rows: null pointer");
+    SWC_CHECK_ARG(B >= 0 && B <= 65535 && T >= 0 && row_bytes > 0 && row_bytes % 16 == 0 && aligned16(src) && aligned16(dst),
+                  "swc_pack_rows: bad shape or alignment");
+    if (B == 0 || T == 0) return SWC_OK;
+    const long per = (long)T * (row_bytes / 16);
+    const unsigned gx = (unsigned)((per + 255) / 256 > 1024 ? 1024 : (per + 255) / 256);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, (uint4*)dst,
+                       row_start, lens, T, (int)(row_bytes / 16));
+    SWC_CHECK_LAUNCH("swc_pack_rows");
     return SWC_OK;
 }
 

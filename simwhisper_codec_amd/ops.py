@@ -88,15 +88,19 @@ def gemm(A, W, M, N, K, *, out=None, out_dtype=None, lda=None, ldw=None, ldc=Non
     return out
 
 
-def attention(qkv, lens, B, T, H, out=None, out_dtype=None):
-    """out_dtype None: same element type as qkv.  torch.float16: f32 qkv in, split-f16 out."""
+def attention(qkv, lens, B, T, H, out=None, out_dtype=None, row_start=None, rows=None):
+    """out_dtype None: same element type as qkv.  torch.float16: f32 qkv in, split-f16 out.
+    row_start (int32 device tensor, 16-bit operands only): packed layout, `rows` = total number of packed rows."""
     lib = _lib.load()
     _chk(qkv, "attention qkv"); _chk(lens, "attention lens", torch.int32)
     od = out_dtype or qkv.dtype
     if out is None:
-        out = torch.empty((B, T, _w(od, H * 64)), device=qkv.device, dtype=od)
+        shape = (B, T, _w(od, H * 64)) if row_start is None else (rows, _w(od, H * 64))
+        out = torch.empty(shape, device=qkv.device, dtype=od)
+    if row_start is not None and not (qkv.dtype in (torch.bfloat16, torch.float16) and od == qkv.dtype and not LEGACY_ATTENTION):
+        raise _lib.SwcError("attention: the packed layout exists for the 16-bit operand kernel only")
     if qkv.dtype in (torch.bfloat16, torch.float16) and od == qkv.dtype and not LEGACY_ATTENTION:
-        _lib.check(lib.swc_attention16(_ptr(qkv), _ptr(out), _ptr(lens), B, T, H, _DT[qkv.dtype], _stream()),
+        _lib.check(lib.swc_attention16(_ptr(qkv), _ptr(out), _ptr(lens), B, T, H, _DT[qkv.dtype], _ptr(row_start), _stream()),
                    "swc_attention16")
     elif od == qkv.dtype:
         _lib.check(lib.swc_attention(_ptr(qkv), _ptr(out), _ptr(lens), B, T, H, _DT[qkv.dtype], _stream()),
@@ -108,14 +112,26 @@ def attention(qkv, lens, B, T, H, out=None, out_dtype=None):
     return out
 
 
-def layernorm(x, w, b, eps, *, B, t_in, C_, t_out=None, lens=None, out=None, out_dtype=torch.float32):
+def layernorm(x, w, b, eps, *, B, t_in, C_, t_out=None, lens=None, out=None, out_dtype=torch.float32, row_start=None):
+    """row_start (int32 device tensor, with lens): x is packed (utterance b's rows start at row_start[b]); out is padded."""
     lib = _lib.load()
     _chk(x, "layernorm x", torch.float32)
     t_out = t_in if t_out is None else t_out
     if out is None:
         out = torch.empty((B, t_out, _w(out_dtype, C_)), device=x.device, dtype=out_dtype)
     _lib.check(lib.swc_layernorm(_ptr(x), _ptr(out), _ptr(w), _ptr(b), _ptr(lens), B, t_in, t_out, C_, eps,
-                                 _DT[out.dtype], _stream()), "swc_layernorm")
+                                 _DT[out.dtype], _ptr(row_start), _stream()), "swc_layernorm")
+    return out
+
+
+def pack_rows(x, row_start, lens, *, B, T, total):
+    """padded [B*T, C] (4-byte elements) -> packed [total, C]: the first lens[b] rows of every utterance, back to back."""
+    lib = _lib.load()
+    _chk(x, "pack_rows x"); _chk(row_start, "pack_rows row_start", torch.int32); _chk(lens, "pack_rows lens", torch.int32)
+    Cw = x.shape[-1]
+    out = torch.empty((total, Cw), device=x.device, dtype=x.dtype)
+    _lib.check(lib.swc_pack_rows(_ptr(x), _ptr(out), _ptr(row_start), _ptr(lens), B, T, Cw * x.element_size(), _stream()),
+               "swc_pack_rows")
     return out
 
 

@@ -333,8 +333,9 @@ def test_length_bucketing_is_exact(tag, precision):
     wavs = [synth.synth_audio(int(16000 * t) + 13 * i, index=950 + i, kind="speech" if i % 2 else "noise").to(DEV)
             for i, t in enumerate(secs)]
     assert len(length_groups(sorted([int(16000 * t) // 320 for t in secs], reverse=True))) > 1  # the case is really ragged
-    keep_rows = m.fused_mlp_min_rows
+    keep_rows, keep_pack = m.fused_mlp_min_rows, m.varlen_packing
     try:
+        m.varlen_packing = False  # (with packing on, ragged calls are not grouped at all)
         # the same kernels on both sides (the fused ConvNeXt kernel is chosen by the number of Vocos frames of a call and
         # rounds its bf16 intermediate in another order than the two-GEMM form): bit-identical
         m.fused_mlp_min_rows = 1 << 40
@@ -349,12 +350,49 @@ def test_length_bucketing_is_exact(tag, precision):
         w2 = m.decode(c1)["syn_wav_list"]
     finally:
         m.length_bucketing = True
-        m.fused_mlp_min_rows = keep_rows
+        m.fused_mlp_min_rows, m.varlen_packing = keep_rows, keep_pack
     for a, b in zip(c0 + w0, c1 + w1):
         assert a.shape == b.shape and torch.equal(a, b)
     for a, b in zip(w1, w2):
         if a.numel():
             assert _relerr(b.cpu().numpy(), a.cpu().numpy()) < (TOL_FP32 if precision == "fp32" else TOL_BF16)
+    if tag == "tiny":
+        want = oracle(tag).encode([w.cpu() for w in wavs], trim=True)["codes_list"]
+        for a, b in zip(c1, want):
+            assert torch.equal(a.cpu().long(), b.long())
+
+
+@pytest.mark.parametrize("tag,precision", [("tiny", "mixed"), ("real", "mixed"), ("real", "bf16")])
+def test_valid_token_packing_is_exact(tag, precision):
+    """Ragged calls run the encoder / decoder transformers on the valid tokens only (packed rows, swc_pack_rows +
+    row_start of swc_attention16 / swc_layernorm): bit-identical codes and waveforms to the padded layout, and the
+    reference's codes (tiny config, oracle)."""
+    from simwhisper_codec_amd import synth
+    m = model(tag, precision)
+    secs = [9.0, 1.1, 4.3, 0.3, 7.7, 2.0, 0.05, 5.5]
+    wavs = [synth.synth_audio(int(16000 * t) + 29 * i, index=970 + i, kind="speech" if i % 2 else "noise").to(DEV)
+            for i, t in enumerate(secs)]
+    keep = (m.varlen_packing, m.length_bucketing)
+    try:
+        m.length_bucketing = False
+        m.varlen_packing = False
+        c0 = m.encode(wavs)["codes_list"]
+        w0 = m.decode(c0)["syn_wav_list"]
+        m.varlen_packing = True
+        packed_calls = []
+        from simwhisper_codec_amd import ops
+        real = ops.pack_rows
+        ops.pack_rows = lambda *a, **k: (packed_calls.append(1), real(*a, **k))[1]
+        try:
+            c1 = m.encode(wavs)["codes_list"]
+            w1 = m.decode(c1)["syn_wav_list"]
+        finally:
+            ops.pack_rows = real
+    finally:
+        m.varlen_packing, m.length_bucketing = keep
+    assert len(packed_calls) == 2  # encoder and decoder transformers both ran packed
+    for a, b in zip(c0 + w0, c1 + w1):
+        assert a.shape == b.shape and torch.equal(a, b)
     if tag == "tiny":
         want = oracle(tag).encode([w.cpu() for w in wavs], trim=True)["codes_list"]
         for a, b in zip(c1, want):

@@ -16,8 +16,9 @@ srt = sorted(lens, reverse=True)
 print("encode groups (tokens):", [(a, b, spec.token_len(srt[a])) for a, b in length_groups([spec.token_len(v) for v in srt])])
 need = [min(srt[0] // 1280, v // 1280 + 64) for v in srt]
 print("decode groups (code frames):", [(a, b, need[a]) for a, b in length_groups([4 * v for v in need])])
-for bucket, ovh in ((False, 0), (True, 5000), (True, 2500), (True, 1200), (True, 600), (False, 0), (True, 5000), (True, 2500), (True, 1200), (True, 600)):
-    m.length_bucketing, m.bucket_overhead_tokens = bucket, float(ovh)
+for pack, bucket in ((False, False), (False, True), (True, False), (True, True)) * 2:
+    m.varlen_packing, m.length_bucketing = pack, bucket
+    ovh = 5000
     for _ in range(2):
         c = m.encode(wavs)["codes_list"]; m.decode(c)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -28,4 +29,4 @@ for bucket, ovh in ((False, 0), (True, 5000), (True, 2500), (True, 1200), (True,
     for _ in range(6):
         m.decode(c)
     torch.cuda.synchronize(); td = (time.perf_counter() - t0) / 6
-    print(f"bucketing={bucket} overhead={ovh}: encode {te*1e3:6.2f} ms  decode {td*1e3:6.2f} ms  = {audio/(te+td):6.0f} audio-s/s ({audio:.0f} s of audio)", flush=True)
+    print(f"packing={pack} bucketing={bucket}: encode {te*1e3:6.2f} ms  decode {td*1e3:6.2f} ms  = {audio/(te+td):6.0f} audio-s/s ({audio:.0f} s of audio)", flush=True)
