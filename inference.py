@@ -9,6 +9,14 @@
 Differences on purpose: `--device` is passed on to encode()/decode() (the reference forgets to),
 file loading for batch i+1 and saving of batch i-1 overlap the GPU work of batch i, and
 `--precision` / `--synthetic_checkpoint` exist because the trained weights cannot be fetched offline.
+
+Several GPUs of one node (BASELINE.json configs[3]): launch the same command under torch.distributed.run
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 inference.py ... --batch_size 32
+
+Rank 0 reads and writes the files; every step takes `--batch_size x world` files, scatters the audio over RCCL / xGMI
+(simwhisper_codec_amd.dist.DataParallelCodec.encode_decode), every GPU encodes + decodes its share, and the waveforms
+come back to rank 0.  Outputs are the files the single-GPU run writes (sharded decode pads to the global maximum).
 """
 import argparse
 import logging
@@ -43,6 +51,8 @@ def build_parser():
     p.add_argument("--precision", type=str, default="mixed", choices=["fp32", "mixed", "mixed_f32", "bf16", "fp8"])
     p.add_argument("--synthetic_checkpoint", action="store_true",
                    help="ignore --checkpoint_path and use the closed-form synthetic weights (offline testing)")
+    p.add_argument("--dist_backend", type=str, default="nccl", help="torch.distributed backend under torch.distributed.run "
+                   "(nccl = RCCL; gloo moves the audio through host memory: tests)")
     return p
 
 
@@ -62,6 +72,9 @@ def load_model(args, device):
 def main(argv=None):
     set_logging()
     args = build_parser().parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        return main_distributed(args, world)
     device = torch.device(args.device)
     generator = load_model(args, device)
     audio_paths = find_audio_files(input_dir=args.input_dir)
@@ -104,6 +117,69 @@ def main(argv=None):
     dt = time.perf_counter() - t0
     logging.info(f"All audio processing completed: {total_audio:.1f} s of audio in {dt:.2f} s "
                  f"({total_audio / max(dt, 1e-9):.1f} x real time incl. file IO)")
+
+
+def main_distributed(args, world):
+    """One process per GPU (torch.distributed.run): rank 0 owns the files, all ranks share the compute."""
+    import torch.distributed as dist
+    from simwhisper_codec_amd.dist import DataParallelCodec
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", 0))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    ngpu = torch.cuda.device_count()
+    device = torch.device("cuda", local % max(ngpu, 1))
+    torch.cuda.set_device(device)
+    if args.dist_backend == "nccl":
+        dist.init_process_group("nccl", device_id=device)
+        comm = None
+    else:
+        dist.init_process_group(args.dist_backend)
+        comm = "cpu"
+    try:
+        generator = load_model(args, device)
+        dp = DataParallelCodec(generator, device, comm_device=comm)
+        bs = args.batch_size * world
+        if rank == 0:
+            audio_paths = find_audio_files(input_dir=args.input_dir)
+            os.makedirs(args.output_dir, exist_ok=True)
+            logging.info(f"Processing {len(audio_paths)} audio files on {world} GPUs, output will be saved to {args.output_dir}")
+            batches = [audio_paths[i:i + bs] for i in range(0, len(audio_paths), bs)]
+        else:
+            batches = None
+        nb = dp._share_ints([len(batches)] if rank == 0 else None)[0]
+        total_audio, t0 = 0.0, time.perf_counter()
+        with ThreadPoolExecutor(max_workers=2) as pool, torch.no_grad():
+            def load(paths):
+                return [load_audio(p, target_sample_rate=generator.input_sample_rate).reshape(-1).pin_memory() for p in paths]
+
+            def save(paths, wavs):
+                for path, wav in zip(paths, wavs):
+                    out = os.path.join(args.output_dir, os.path.splitext(os.path.basename(path))[0] + ".wav")
+                    save_audio(out, wav.reshape(1, -1), sample_rate=generator.output_sample_rate)
+            nxt = pool.submit(load, batches[0]) if rank == 0 and nb else None
+            pending = None
+            for bi in range(nb):
+                wav_list = None
+                if rank == 0:
+                    logging.info(f"Processing batch {bi + 1}/{nb}, files: {batches[bi]}")
+                    cpu_wavs = nxt.result()
+                    nxt = pool.submit(load, batches[bi + 1]) if bi + 1 < nb else None
+                    wav_list = [w.to(device, non_blocking=True) for w in cpu_wavs]
+                out = dp.encode_decode(wav_list, overlap_seconds=10)
+                if rank == 0:
+                    logging.info(f"Decoding completed, generated waveform lengths: {[len(w) for w in out['syn_wav_list']]} samples")
+                    host = [w.cpu() for w in out["syn_wav_list"]]
+                    total_audio += sum(len(w) for w in host) / generator.output_sample_rate
+                    if pending is not None:
+                        pending.result()
+                    pending = pool.submit(save, batches[bi], host)
+            if pending is not None:
+                pending.result()
+        if rank == 0:
+            dt = time.perf_counter() - t0
+            logging.info(f"All audio processing completed: {total_audio:.1f} s of audio in {dt:.2f} s on {world} GPUs "
+                         f"({total_audio / max(dt, 1e-9):.1f} x real time incl. file IO)")
+    finally:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
