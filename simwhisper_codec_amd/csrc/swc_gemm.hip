@@ -37,6 +37,9 @@ namespace {
 
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+#ifdef SWC_GEMM_STAMP
+__device__ unsigned long long g_stamps[512 * 8 * 8];  // [workgroup][wave][compute, vmcnt wait, barrier wait, slices, epilogue, tiles, tail, -]
+#endif
 
 // 16 bytes per lane, global -> LDS (global_load_lds_dwordx4).  `lds_addr` is the wave-uniform LDS byte
 // address; lane l lands at lds_addr + 16 l.  Written as inline asm on purpose: hipcc drains a
@@ -77,6 +80,7 @@ __device__ __forceinline__ int swz_rb(int row) { return RB == 128 ? swz(row) : s
 template <int RB>
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * RB + ((chunk ^ swz_rb<RB>(row)) << 4); }
 
+
 struct GemmP {
     const char* A;
     const char* W;
@@ -97,10 +101,83 @@ struct GemmP {
 
 // Epilogue shared by all geometries.  Transposed product: lane (fr, fh) holds, for activation row
 // 16i + fr of its wave's slab, the 16 contiguous output columns 16fh + 4j + e.
-template <typename OutT, int MT>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4], int bm, int bn, int wr, int wc, int fr,
-                                              int fh) {
-    // ---- epilogue: lane (fr, fh) holds, for row 16i + fr, columns 16fh + 4j + e of its 64-column slab
+constexpr int EPI_TP = 68;                       // row pitch (floats) of a wave's transpose block: conflict-free b128 writes
+constexpr int EPI_WAVE_BYTES = 16 * EPI_TP * 4;  // 16 rows x 64 columns per wave
+
+template <typename OutT>
+__device__ __forceinline__ float epi_act(float x) {
+    return (__is_same(OutT, bf16_t) || __is_same(OutT, fp8_t)) ? gelu_fast(x) : (__is_same(OutT, f16s_t) ? gelu_as(x) : gelu_erf(x));
+}
+
+// Coalesced epilogue for a wave whose 64-column slab lies inside N: every 16 x 64 accumulator block goes through the
+// wave's own LDS scratch (no workgroup barrier: one wave, LDS operations of a wave complete in order) and comes back
+// with lane l on row (l >> 4) + 4k, columns 4 (l & 15) .. + 3: one wave-instruction then covers 4 rows x 256 contiguous
+// bytes (f32), the residual is read and the output written in whole 64-byte sectors.  In the accumulator layout a lane
+// owns 16 contiguous columns of ONE row, so one instruction touched 64 separate 16-byte pieces: the f32 epilogue of a
+// 192 x 256 tile took 24k cycles on an idle chip (40k with every CU in its epilogue: 60 % of the out-proj GEMM,
+// profiles/r02_gemm_stamps.txt).  Same arithmetic per element, in the same order, as the direct path below.
+template <typename OutT, int MT, bool GELU>
+__device__ __forceinline__ void gemm_epilogue_slab(const GemmP& p, f32x4 (&acc)[MT][4], int row0, int colw, int fr, int fh,
+                                                   float* tbuf, float& amax) {
+    int lane = fr + 16 * fh;
+    // opaque to the optimiser: everything below depends on it and is therefore computed HERE, once per tile; hoisted out
+    // of the persistent tile loop these per-lane addresses stayed live through the K loop, which has no register to spare
+    // (they were spilled and re-loaded in every slice)
+    asm volatile("" : "+v"(lane));
+    const int tr = lane >> 4, tc = (lane & 15) * 4;
+    const int col = colw + tc;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), g4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + col);
+    if (p.gamma) g4 = *reinterpret_cast<const float4*>(p.gamma + col);
+    float* wr_p = tbuf + (lane & 15) * EPI_TP + (lane >> 4) * 16;
+    const float* rd_p = tbuf + tr * EPI_TP + tc;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int rbase = row0 + 16 * i + tr;
+        float4 r4[4];
+        if (p.residual) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = rbase + 4 * k;
+                r4[k] = row < p.M ? *reinterpret_cast<const float4*>(p.residual + (long)row * p.ldr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(wr_p + 4 * j) = acc[i][j];
+        f32x4 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = *reinterpret_cast<const f32x4*>(rd_p + 4 * k * EPI_TP);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = rbase + 4 * k;
+            float v0 = t[k][0] * p.alpha + b4.x, v1 = t[k][1] * p.alpha + b4.y, v2 = t[k][2] * p.alpha + b4.z, v3 = t[k][3] * p.alpha + b4.w;
+            if constexpr (GELU) { v0 = epi_act<OutT>(v0); v1 = epi_act<OutT>(v1); v2 = epi_act<OutT>(v2); v3 = epi_act<OutT>(v3); }
+            v0 *= g4.x; v1 *= g4.y; v2 *= g4.z; v3 *= g4.w;
+            if (p.residual) { v0 += r4[k].x; v1 += r4[k].y; v2 += r4[k].z; v3 += r4[k].w; }
+            if (row >= p.M) continue;
+            if constexpr (__is_same(OutT, f16s_t)) {
+                const float os = p.out_scale;
+                f16s_store4(reinterpret_cast<unsigned short*>(p.C) + (long)row * p.ldc * 2, col, v0 * os, v1 * os, v2 * os, v3 * os, amax);
+            } else if constexpr (sizeof(OutT) == 4) {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)row * p.ldc + col) = make_float4(v0, v1, v2, v3);
+            } else if constexpr (sizeof(OutT) == 1) {
+                const float os = p.out_scale;
+                *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.C) + (long)row * p.ldc + col) = fp8_pack4(v0 * os, v1 * os, v2 * os, v3 * os, amax);
+            } else {
+                uint2 u;
+                u.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
+                u.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (long)row * p.ldc + col) = u;
+            }
+        }
+    }
+}
+
+// Direct epilogue (slabs cut by N, unaligned pointers, split-f16 outputs): lane (fr, fh) holds, for row 16i + fr, columns
+// 16fh + 4j + e of its wave's 64-column slab.
+template <typename OutT, int MT, int GELU>  // GELU: 0 none, 1 always, 2 by p.act (one body)
+__device__ __forceinline__ void gemm_epilogue_direct(const GemmP& p, f32x4 (&acc)[MT][4], int bm, int bn, int wr, int wc, int fr,
+                                                     int fh) {
     OutT* C = reinterpret_cast<OutT*>(p.C);
     const int col0 = bn + wc * 64 + 16 * fh;
     const bool vec_ok = (col0 + 16 <= p.N) && ((p.ldc & (sizeof(OutT) == 1 ? 15 : 3)) == 0) &&
@@ -124,11 +201,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = acc[i][j][e] * p.alpha + bv[4 * j + e];
-                if (p.act == SWC_ACT_GELU) x = (__is_same(OutT, bf16_t) || __is_same(OutT, fp8_t)) ? gelu_fast(x) : (__is_same(OutT, f16s_t) ? gelu_as(x) : gelu_erf(x));
-                v[4 * j + e] = x * gv[4 * j + e];
-            }
+            for (int e = 0; e < 4; ++e) v[4 * j + e] = acc[i][j][e] * p.alpha + bv[4 * j + e];
+        if constexpr (GELU == 1) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) v[c] = epi_act<OutT>(v[c]);
+        } else if constexpr (GELU == 2) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                if (p.act == SWC_ACT_GELU) v[c] = epi_act<OutT>(v[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] *= gv[c];
         if constexpr (sizeof(OutT) == sizeof(f16s_t) && !__is_same(OutT, bf16_t)) {
             // split-f16 output: the lane's 16 columns sit inside one 32-block (col0 % 16 == 0, N % 32 == 0)
             if (col0 + 16 <= p.N) {
@@ -205,6 +288,39 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
     if constexpr (__is_same(OutT, fp8_t)) sat_commit(p.sat, 1, amax, SWC_FP8_LIMIT);
 }
 
+// The activation is a template parameter behind a wave-uniform branch: as a run-time select inside one body hipcc evaluates
+// the GELU of every element of every GEMM and selects afterwards — the GEMMs without an activation (qkv, out-proj, fc2,
+// pwconv2, every conv) paid 10 (bf16) to 40 (erff) VALU instructions per output for nothing (tools/gemm_stamps.py).
+template <typename OutT, int MT, bool SLAB>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4], int bm, int bn, int wr, int wc, int fr,
+                                              int fh, float* tbuf) {
+    const bool gelu = p.act == SWC_ACT_GELU;
+    // f32 outputs (residual stream: out-proj, fc2, pwconv2, heads) take the transposed path: +9 ... +15 % on those GEMMs.
+    // 16-bit outputs keep the direct one: a lane's 16 columns are 32 contiguous bytes there, the transposed path measured
+    // no faster without and 6 - 8 % slower with the GELU, and split-f16 conversion leaves no register for it
+    if constexpr (SLAB && sizeof(OutT) == 4 && !__is_same(OutT, f16s_t)) {
+        const int colw = bn + wc * 64;
+        const bool al16 = ((reinterpret_cast<uintptr_t>(p.C) | reinterpret_cast<uintptr_t>(p.residual) |
+                            reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.gamma)) & 15) == 0;
+        const bool ok = tbuf && colw + 64 <= p.N && al16 && (p.ldc & (sizeof(OutT) == 1 ? 15 : 3)) == 0 &&
+                        (!p.residual || (p.ldr & 3) == 0);
+        if (__builtin_amdgcn_readfirstlane((int)ok)) {  // wave-uniform by construction
+            float amax = 0.f;
+            if (gelu) gemm_epilogue_slab<OutT, MT, true>(p, acc, bm + wr * (MT * 16), colw, fr, fh, tbuf, amax);
+            else gemm_epilogue_slab<OutT, MT, false>(p, acc, bm + wr * (MT * 16), colw, fr, fh, tbuf, amax);
+            if constexpr (__is_same(OutT, fp8_t)) sat_commit(p.sat, 1, amax, SWC_FP8_LIMIT);
+            return;
+        }
+    }
+    if constexpr (__is_same(OutT, f16s_t) && MT == 8) {
+        // the 256-row split-f16 kernel (fc1: always GELU) has no register for two bodies: the K loop spilled
+        gemm_epilogue_direct<OutT, MT, 2>(p, acc, bm, bn, wr, wc, fr, fh);
+    } else {
+        if (gelu) gemm_epilogue_direct<OutT, MT, 1>(p, acc, bm, bn, wr, wc, fr, fh);
+        else gemm_epilogue_direct<OutT, MT, 0>(p, acc, bm, bn, wr, wc, fr, fh);
+    }
+}
+
 // PLAIN: one tap, K a multiple of the slice, no stride / padding / row remap — the hot GEMMs.  A separate
 // instantiation so that the implicit-conv bookkeeping (~32 VGPRs) does not sit in the hot loop's register budget.
 template <int MODE, typename OutT, int MT, int WAVES_M, int WAVES_N, bool PLAIN, int RB = 128>
@@ -213,6 +329,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     constexpr int CPR = RB / 16;   // 16-byte chunks per row
     constexpr int NG = RB / 64;    // 64-byte k-groups per slice
     static_assert(RB == 128 || (RB == 64 && MODE != SWC_F16S), "split-f16 needs hi|lo in one 128-byte row");
+    static_assert(WAVES_M * WAVES_N * EPI_WAVE_BYTES <= (WAVES_M * MT * 16 + WAVES_N * 64) * RB, "epilogue scratch must fit one stage");
     constexpr bool BF16 = MODE == SWC_BF16;
     constexpr bool F16S = MODE == SWC_F16S;
     constexpr bool FP8 = MODE == SWC_FP8;
@@ -365,10 +482,31 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         }
     };
     // the LDS-DMA is invisible to the compiler: order it ourselves
+#ifdef SWC_GEMM_STAMP
+    // diagnostic build only (tools/gemm_stamps.py): where the waves of the K loop wait.  Stamps go to g_stamps, which no
+    // other code reads.
+    unsigned long long st_last = 0, st_cmp = 0, st_vm = 0, st_bar = 0, st_n = 0;
+    auto stamp = [&]() -> unsigned long long {
+        unsigned long long t;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        return t;
+    };
+    auto dma_fence = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long t1 = stamp();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t2 = stamp();
+        __syncthreads();
+        const unsigned long long t3 = stamp();
+        if (st_last) { st_cmp += t1 - st_last; st_vm += t2 - t1; st_bar += t3 - t2; st_n += 1; }
+        st_last = t3;
+    };
+#else
     auto dma_fence = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
+#endif
 
     f32x4 acc[MT][4];
 #pragma unroll
@@ -480,7 +618,22 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         setup_tile(tl);
         stage_slice(0, 0);
     }
-    gemm_epilogue<OutT, MT>(p, acc, bm_done, bn_done, wr, wc, fr, fh);
+#ifdef SWC_GEMM_STAMP
+    const unsigned long long st_e0 = stamp();
+#endif
+    // the other stage buffer is free until the fence below (the next tile's first slice goes to stage 0): per-wave scratch
+    // (not for 256-row tiles: no register to spare, their K loops spilled or lost their schedule)
+    gemm_epilogue<OutT, MT, MT < 8>(p, acc, bm_done, bn_done, wr, wc, fr, fh,
+                            reinterpret_cast<float*>(smem + STAGE_BYTES + wave_u * EPI_WAVE_BYTES));
+#ifdef SWC_GEMM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st_e1 = stamp();
+    if (lane == 0 && blockIdx.x < 512) {
+        unsigned long long* o = g_stamps + ((long)blockIdx.x * 8 + wave) * 8;
+        o[0] += st_cmp; o[1] += st_vm; o[2] += st_bar; o[3] += st_n; o[4] += st_e1 - st_e0; o[5] += 1; o[6] += st_e0 - st_last;
+    }
+    st_cmp = st_vm = st_bar = st_n = 0; st_last = 0;
+#endif
     if (!more) break;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -640,3 +793,15 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     SWC_CHECK_LAUNCH("swc_gemm");
     return SWC_OK;
 }
+
+#ifdef SWC_GEMM_STAMP
+extern "C" int swc_debug_stamps(void* host_out, int reset) {
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 512 * 8 * 8) != hipSuccess) return -1;
+    if (reset) {
+        static unsigned long long zeros[512 * 8 * 8];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), zeros, sizeof(zeros)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
