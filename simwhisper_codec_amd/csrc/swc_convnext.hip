@@ -42,6 +42,9 @@ constexpr int CX_TLD = CX_C + 4;  // row pitch (floats) of the epilogue transpos
 #ifndef CX_ABL
 #define CX_ABL 0
 #endif
+#ifndef CX_EPI_PREFETCH
+#define CX_EPI_PREFETCH 1
+#endif
 
 __device__ __forceinline__ void cx_glds16(const void* gsrc, unsigned lds_addr) {
     unsigned keep;
@@ -410,6 +413,18 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
+#if CX_EPI_PREFETCH
+        // the residual rows of this pass first: 32 independent 16-byte loads per lane, in flight across the LDS round trip
+        // (the arithmetic registers of the slice loop are free here)
+        float4 rr[16][2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long row = (long)row0 + 64 * p + 16 * w + i;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf)
+                rr[i][hf] = row < M ? *reinterpret_cast<const float4*>(x + row * CX_C + 256 * hf + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#endif
 #pragma unroll
         for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -421,7 +436,11 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
                         make_float4(t[4 * g], t[4 * g + 1], t[4 * g + 2], t[4 * g + 3]);
                 }
         __syncthreads();
+#if CX_EPI_PREFETCH
+#pragma unroll
+#else
 #pragma unroll 4
+#endif
         for (int i = 0; i < 16; ++i) {
             const int fl = 16 * w + i;
             const long row = (long)row0 + 64 * p + fl;
@@ -429,7 +448,11 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const float4 v = *reinterpret_cast<const float4*>(tl + fl * CX_TLD + 256 * hf + 4 * lane);
+#if CX_EPI_PREFETCH
+                    float4 r = rr[i][hf];
+#else
                     float4 r = *reinterpret_cast<const float4*>(x + row * CX_C + 256 * hf + 4 * lane);
+#endif
                     r.x += g4[hf].x * (v.x + c4[hf].x); r.y += g4[hf].y * (v.y + c4[hf].y);
                     r.z += g4[hf].z * (v.z + c4[hf].z); r.w += g4[hf].w * (v.w + c4[hf].w);
                     *reinterpret_cast<float4*>(xo + row * CX_C + 256 * hf + 4 * lane) = r;
