@@ -332,9 +332,33 @@ void dwconv7_ln_kernel(const float* __restrict__ x, OutT* __restrict__ y,
 
 // ------------------------------------------------------ anti-aliased SnakeBeta
 struct Filt12 { float f[12]; };
-constexpr int SN_TS = 8;   // outputs per thread strip (6 halo pairs are recomputed per strip: short strips trade 1.75x the sines for 4x the parallelism on these small tensors)
 
-template <typename OutT>
+// sin(a)^2 to f32 accuracy (|error| < 1.5e-7, a few ulp of the f32 product sinf(a) * sinf(a)) in 16 VALU instructions,
+// against ~50 for libm's sinf, which made the snake kernel sine-bound: a = q pi/2 + r with |r| <= pi/4 (three-constant
+// Cody-Waite reduction, exact for |q| < 2^15), sin^2 r by its Taylor series in r^2 (six terms: truncation < 3e-9), and
+// sin^2 a = sin^2 r for even q, 1 - sin^2 r for odd q — no quadrant-dependent polynomial, no sign logic.
+__device__ __forceinline__ float sin2_f32(float a) {
+    if (fabsf(a) > 8192.0f) {  // beyond the reduction's exact range (never on this path's activations): libm
+        const float sn = sinf(a);
+        return sn * sn;
+    }
+    const float q = rintf(a * 0.63661977236758134308f);
+    float r = fmaf(-q, 1.5703125f, a);
+    r = fmaf(-q, 4.837512969970703125e-4f, r);
+    r = fmaf(-q, 7.54978995489188216e-8f, r);
+    const float u = r * r;
+    float p = fmaf(u, -4.2755787e-6f, 1.4109347e-4f);   // -2048 / 12!,  512 / 10!
+    p = fmaf(p, u, -3.1746032e-3f);                      // -128 / 8!
+    p = fmaf(p, u, 4.4444444e-2f);                       //  32 / 6!
+    p = fmaf(p, u, -3.3333334e-1f);                      //  -8 / 4!
+    p = fmaf(p, u, 1.0f);
+    const float s2 = u * p;
+    return ((int)q & 1) ? 1.0f - s2 : s2;
+}
+// SN_TS outputs per thread strip; 6 halo pairs are recomputed per strip (1.75x the activations at 8).  Longer strips do
+// less arithmetic but measured SLOWER on these small tensors (16: 21.1 us against 18.2 us at 8 for (32, 189, 512)): with a
+// few waves per SIMD the long dependent chains of the activation are not covered, so parallelism wins over the halo.
+template <typename OutT, int SN_TS>
 __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__ x, OutT* __restrict__ y,
                                                        const float* __restrict__ alpha,
                                                        const float* __restrict__ beta, Filt12 F, int T,
@@ -356,9 +380,13 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
     // up[2u]   = 2 * sum_{d=-3..2} x[u+d] f[5-2d];  up[2u+1] = 2 * sum_{d=-2..3} x[u+d] f[6-2d]
     auto act = [&](float v) -> float {
         // bf16 outputs (decode side of the bf16-class presets) take the hardware sine (v_sin_f32, |error| ~1e-6 on
-        // these arguments); f32 / split-f16 outputs keep the exact sinf: the down-sampler feeds the FSQ rounding
-        const float sn = __is_same(OutT, bf16_t) ? __sinf(v * al) : sinf(v * al);
-        return v + ib * (sn * sn);
+        // these arguments); f32 / split-f16 outputs (the down-sampler feeds the FSQ rounding) take sin2_f32 below
+        if constexpr (__is_same(OutT, bf16_t)) {
+            const float sn = __sinf(v * al);
+            return v + ib * (sn * sn);
+        } else {
+            return v + ib * sin2_f32(v * al);
+        }
     };
     // a-window for output t: a[clamp(2t - 5 + k)], k = 0..11  => pairs u = t-3 .. t+3 (partially)
     // Keep a ring of activated pairs: A0[u], A1[u] for u in [t-3, t+3].
@@ -391,10 +419,54 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
             pair(u, e0, e1);
         }
     };
+    float amax = 0.f;
+    auto emit = [&](int t, float o) {
+        if constexpr (__is_same(OutT, f16s_t)) {
+            unsigned short hi, lo;
+            f16s_split(o * SWC_F16S_ACT_SCALE, hi, lo, amax);
+            unsigned short* rp = reinterpret_cast<unsigned short*>(yb) + (long)t * 2 * C + f16s_col(c);
+            rp[0] = hi;
+            rp[32] = lo;
+        } else {
+            store_out<OutT>(yb + (long)t * C + c, o);
+        }
+    };
+    // Interior strips (every up-sample pair t0 - 3 .. t0 + SN_TS + 2 exists): the strip's 20 inputs are requested at
+    // once and everything else runs from registers.  The generic loop below asks for 7 inputs per pair, one pair after
+    // the other: 9 dependent memory round trips per strip made the kernel latency-bound (11 - 14 % of the HBM roofline
+    // with the hardware sine as with libm's), not sine-bound.
+    if (t0 >= 3 && t0 + SN_TS + 2 <= T - 1) {  // block-uniform
+        constexpr int NP = SN_TS + 6;           // pairs
+        float xw[NP + 6];
+#pragma unroll
+        for (int k = 0; k < NP + 6; ++k) xw[k] = X(t0 - 6 + k);
+        float P0[NP], P1[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int d = -3; d <= 2; ++d) s0 += xw[m + d + 3] * F.f[5 - 2 * d];
+#pragma unroll
+            for (int d = -2; d <= 3; ++d) s1 += xw[m + d + 3] * F.f[6 - 2 * d];
+            P0[m] = act(2.0f * s0);
+            P1[m] = act(2.0f * s1);
+        }
+#pragma unroll
+        for (int tt = 0; tt < SN_TS; ++tt) {
+            float o = 0.f;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int m = k + 1 + 2 * tt;
+                o += ((m & 1) ? P1[m >> 1] : P0[m >> 1]) * F.f[k];
+            }
+            emit(t0 + tt, o);
+        }
+        sat_commit_out<OutT>(sat, amax);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 6; ++k) pair_clamped(t0 - 3 + k, A0[k], A1[k]);
     const int tend = (t0 + SN_TS < T) ? t0 + SN_TS : T;
-    float amax = 0.f;
     for (int t = t0; t < tend; ++t) {
         pair_clamped(t + 3, A0[6], A1[6]);
         // out[t] = sum_k a[2t-5+k] f[k]; 2t-5 = 2(t-3)+1 -> starts at A1[0]
@@ -405,15 +477,7 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
             const float av = (m & 1) ? A1[m >> 1] : A0[m >> 1];
             o += av * F.f[k];
         }
-        if constexpr (__is_same(OutT, f16s_t)) {
-            unsigned short hi, lo;
-            f16s_split(o * SWC_F16S_ACT_SCALE, hi, lo, amax);
-            unsigned short* rp = reinterpret_cast<unsigned short*>(yb) + (long)t * 2 * C + f16s_col(c);
-            rp[0] = hi;
-            rp[32] = lo;
-        } else {
-            store_out<OutT>(yb + (long)t * C + c, o);
-        }
+        emit(t, o);
 #pragma unroll
         for (int k = 0; k < 6; ++k) { A0[k] = A0[k + 1]; A1[k] = A1[k + 1]; }
     }
@@ -838,12 +902,12 @@ extern "C" int swc_snake_aa(const float* x, void* y, const float* alpha, const f
     if (B <= 0 || T <= 0 || C <= 0) return SWC_OK;
     Filt12 F;
     for (int i = 0; i < 12; ++i) F.f[i] = filt_host12[i];
-    dim3 grid(nblk(C, 256), nblk(T, SN_TS), B);
     hipStream_t s = (hipStream_t)stream;
+    dim3 grid(nblk(C, 256), nblk(T, 8), B);
     OUT_DISPATCH3(y_dtype,
-                  hipLaunchKernelGGL(snake_aa_kernel<float>, grid, dim3(256), 0, s, x, (float*)y, alpha, beta, F, T, C, swc_sat_counter()),
-                  hipLaunchKernelGGL(snake_aa_kernel<bf16_t>, grid, dim3(256), 0, s, x, (bf16_t*)y, alpha, beta, F, T, C, swc_sat_counter()),
-                  hipLaunchKernelGGL(snake_aa_kernel<f16s_t>, grid, dim3(256), 0, s, x, (f16s_t*)y, alpha, beta, F, T, C, swc_sat_counter()));
+                  hipLaunchKernelGGL((snake_aa_kernel<float, 8>), grid, dim3(256), 0, s, x, (float*)y, alpha, beta, F, T, C, swc_sat_counter()),
+                  hipLaunchKernelGGL((snake_aa_kernel<bf16_t, 8>), grid, dim3(256), 0, s, x, (bf16_t*)y, alpha, beta, F, T, C, swc_sat_counter()),
+                  hipLaunchKernelGGL((snake_aa_kernel<f16s_t, 8>), grid, dim3(256), 0, s, x, (f16s_t*)y, alpha, beta, F, T, C, swc_sat_counter()));
     SWC_CHECK_LAUNCH("swc_snake_aa");
     return SWC_OK;
 }
