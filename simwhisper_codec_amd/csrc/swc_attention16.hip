@@ -42,6 +42,21 @@ __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 c) 
                                                       *reinterpret_cast<const f16x8*>(&b), c, 0, 0, 0);
 }
 
+// two f32 -> one dword of two 16-bit values (RNE) in ONE instruction (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32): as a vector
+// conversion, not inline asm — the operands come straight from v_exp_f32, and only for instructions it knows does hipcc
+// insert the wait state a transcendental result needs before its first use (an asm form returned NaNs)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2n __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+    const bf16x2n r = __builtin_convertvector((f32x2){lo, hi}, bf16x2n);
+    return *reinterpret_cast<const unsigned*>(&r);
+}
+__device__ __forceinline__ unsigned pack2_f16(float lo, float hi) {
+    const f16x2 r = __builtin_convertvector((f32x2){lo, hi}, f16x2);
+    return *reinterpret_cast<const unsigned*>(&r);
+}
+
 constexpr int QB16 = 128;  // queries per workgroup
 constexpr int KT16 = 64;   // keys per tile
 
@@ -142,7 +157,14 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float m_run[2] = {-INFINITY, -INFINITY};
+    // Row sums of P on the matrix pipe (the softmax is VALU-bound at head_dim 64: 250 VALU against 32 MFMA issue slots per
+    // key tile in the bf16 kernel): l^T = ONES[16 x keys] P^T[keys x q] accumulates beside O^T and is rescaled with it;
+    // every row of the tile holds the sum of the operands actually multiplied into O (rounded P, hi + lo for split-f16),
+    // already complete over the wave — no per-element adds, no cross-lane reduction at the end.
+    f32x4 lacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    const unsigned one2 = PLANES == 1 ? 0x3F803F80u : 0x3C003C00u;  // (1.0, 1.0) as bf16 / f16
+    const uint4 ones = make_uint4(one2, one2, one2, one2);
     // Softmax exponentials: raw scores (split-f16: still carrying the operand scales 64 * 64), running maximum in
     // the same raw units, and p = 2^((s - m) * c) with c = scale * log2 e.  The subtraction comes FIRST: it is exact
     // (or rounds at the size of the difference), so the only new error is the rounding of the product, relative
@@ -214,40 +236,37 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
             const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c_exp);
             m_run[qt] = m_new;
             const float m_sub = m_new - m_off;
-            float psum = 0.f;
+            const float mc = m_sub * c_exp;
+            (void)mc;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f((s[qt][ks][e] - m_sub) * c_exp);
-                    s[qt][ks][e] = pv;
-                    psum += pv;
+                    // bf16 (decode side): one fma; split-f16 keeps the subtraction first (see above: the encoder's indices)
+                    s[qt][ks][e] = PLANES == 1 ? __builtin_amdgcn_exp2f(fmaf(s[qt][ks][e], c_exp, -mc))
+                                               : __builtin_amdgcn_exp2f((s[qt][ks][e] - m_sub) * c_exp);
                 }
-            l_run[qt] = l_run[qt] * alpha + psum;
+            lacc[qt] *= alpha;
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) o[qt][dt] *= alpha;
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
-                unsigned short h[8], lo[8];
+                unsigned h[4], lo[4];
+                (void)lo;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float pv = s[qt][2 * pr + (j >> 2)][j & 3];
+                for (int j2 = 0; j2 < 4; ++j2) {  // pairs (2 j2, 2 j2 + 1) of the 8 keys of this k-step
+                    const float p0 = s[qt][2 * pr + (j2 >> 1)][2 * (j2 & 1)], p1 = s[qt][2 * pr + (j2 >> 1)][2 * (j2 & 1) + 1];
                     if constexpr (PLANES == 1) {
-                        h[j] = f32_to_bf16(pv);
+                        h[j2] = pack2_bf16(p0, p1);
                     } else {
                         // p * 2048 <= 2048: no saturation clamp needed here
-                        const float ps = pv;
-                        const _Float16 hh = (_Float16)ps;
-                        const _Float16 ll = (_Float16)(ps - (float)hh);
-                        h[j] = *reinterpret_cast<const unsigned short*>(&hh);
-                        lo[j] = *reinterpret_cast<const unsigned short*>(&ll);
+                        h[j2] = pack2_f16(p0, p1);
+                        const f16x2 hh = *reinterpret_cast<const f16x2*>(&h[j2]);
+                        lo[j2] = pack2_f16(p0 - (float)hh[0], p1 - (float)hh[1]);
                     }
                 }
-                pf[qt][pr][0] = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16),
-                                           h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
-                if constexpr (PLANES == 2)
-                    pf[qt][pr][1] = make_uint4(lo[0] | ((unsigned)lo[1] << 16), lo[2] | ((unsigned)lo[3] << 16),
-                                               lo[4] | ((unsigned)lo[5] << 16), lo[6] | ((unsigned)lo[7] << 16));
+                pf[qt][pr][0] = make_uint4(h[0], h[1], h[2], h[3]);
+                if constexpr (PLANES == 2) pf[qt][pr][1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
             }
         }
         // O^T[d][q] += V^T[d][key] P^T[key][q]
@@ -282,6 +301,13 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
                     o[qt][dt] = a;
                 }
             }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                if constexpr (PLANES == 2) lacc[qt] = mma16<PLANES>(ones, pf[qt][pr][1], lacc[qt]);
+                lacc[qt] = mma16<PLANES>(ones, pf[qt][pr][0], lacc[qt]);
+            }
         fence();
     };
     for (int kt = 0; kt + 1 < ntile; ++kt) tile(kt, std::false_type{});
@@ -289,9 +315,7 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
 
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        float l = l_run[qt];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        const float l = lacc[qt][0];  // every row of the tile holds the sum for query column fr
         // split-f16: acc = sum (P * 2048) (V * 64); the output is written at the activation scale 64
         const float inv = l > 0.f ? 1.0f / l : 0.f;  // split-f16: P and its row sum both carry the factor 2048
         const int q = q0 + wave * 32 + qt * 16 + fr;

@@ -57,7 +57,10 @@ __device__ __forceinline__ void cx_glds16(const void* gsrc, unsigned lds_addr) {
 }
 
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    unsigned r;  // one v_cvt_pk_bf16_f32 for the pair (RNE; hipcc has no builtin and emits two conversions + shift + or)
+    // one v_cvt_pk_bf16_f32 for the pair (RNE).  Only for operands that a plain VALU instruction produced (here: the fma
+    // that ends gelu_fast): hipcc does not insert, for an asm statement, the wait state that a transcendental result needs
+    // before its first use (swc_attention16 uses the vector-conversion form for that reason).
+    unsigned r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
