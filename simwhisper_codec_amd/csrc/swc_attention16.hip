@@ -57,16 +57,18 @@ __device__ __forceinline__ unsigned pack2_f16(float lo, float hi) {
     return *reinterpret_cast<const unsigned*>(&r);
 }
 
-constexpr int QB16 = 128;  // queries per workgroup
 
 // KT16: keys per tile (64, or 128 for the bf16 kernel: half the fences and dependent softmax chains per key)
-template <int PLANES, int KT16>
-__global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__ qkv, unsigned short* __restrict__ out,
+// NQT: 16-query MFMA tiles per wave (2: 128 queries per workgroup; 1: 64 — half the registers, twice the waves per SIMD)
+template <int PLANES, int KT16, int NQT>
+__global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const char* __restrict__ qkv, unsigned short* __restrict__ out,
                                                         const int* __restrict__ lens, int T, int H,
                                                         const int* __restrict__ row_start) {
     constexpr int ROWB = 128 * PLANES;    // bytes of one (token, head) row: 64 bf16, or [32 hi|32 lo|32 hi|32 lo] f16
     constexpr int CPR = ROWB / 16;        // 16-byte chunks per row
     constexpr int TILE = KT16 * ROWB;     // bytes of a K or V tile
+    constexpr int QB16 = 64 * NQT;        // queries per workgroup
+    constexpr int QW = 16 * NQT;          // queries per wave
     constexpr int NKS = KT16 / 16;        // 16-key score sub-tiles per tile
     constexpr int NPR = KT16 / 32;        // 32-key k-steps of the PV product per tile
     constexpr int NI = TILE / 1024;       // LDS-DMA wave-instructions per tile
@@ -105,17 +107,17 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
 
     if (q0 >= len) {  // whole block is padding: defined, finite output
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) store_o(q0 + wave * 32 + qt * 16 + fr, dt * 16 + fh * 4, 0.f, 0.f, 0.f, 0.f);
+            for (int dt = 0; dt < 4; ++dt) store_o(q0 + wave * QW + qt * 16 + fr, dt * 16 + fh * 4, 0.f, 0.f, 0.f, 0.f);
         return;
     }
 
     // ---- Q fragments (B operand of S^T): [qt][g][plane]
-    uint4 qf[2][2][PLANES];
+    uint4 qf[NQT][2][PLANES];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        int q = q0 + wave * 32 + qt * 16 + fr;
+    for (int qt = 0; qt < NQT; ++qt) {
+        int q = q0 + wave * QW + qt * 16 + fr;
         q = q < qlim ? q : qlim - 1;
         const char* qp = base + (long)q * ldb;
 #pragma unroll
@@ -154,17 +156,21 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
         __syncthreads();
     };
 
-    f32x4 o[2][4];
+    f32x4 o[NQT][4];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float m_run[2] = {-INFINITY, -INFINITY};
+    float m_run[NQT];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) m_run[qt] = -INFINITY;
     // Row sums of P on the matrix pipe (the softmax is VALU-bound at head_dim 64: 250 VALU against 32 MFMA issue slots per
     // key tile in the bf16 kernel): l^T = ONES[16 x keys] P^T[keys x q] accumulates beside O^T and is rescaled with it;
     // every row of the tile holds the sum of the operands actually multiplied into O (rounded P, hi + lo for split-f16),
     // already complete over the wave — no per-element adds, no cross-lane reduction at the end.
-    f32x4 lacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 lacc[NQT];
+#pragma unroll
+    for (int qt = 0; qt < NQT; ++qt) lacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned one2 = PLANES == 1 ? 0x3F803F80u : 0x3C003C00u;  // (1.0, 1.0) as bf16 / f16
     const uint4 ones = make_uint4(one2, one2, one2, one2);
     // Softmax exponentials: raw scores (split-f16: still carrying the operand scales 64 * 64), running maximum in
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
         const int k0 = kt * KT16;
 
         // S^T[key][q] for 4 key sub-tiles x 2 query tiles
-        f32x4 s[2][NKS];
+        f32x4 s[NQT][NKS];
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             const int row = ks * 16 + fr;
@@ -204,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
                     kf[g][pl] = *reinterpret_cast<const uint4*>(sK + row * ROWB + ((c ^ krow_swz(row)) << 4));
                 }
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < NQT; ++qt) {
                 f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
@@ -218,9 +224,9 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
             }
         }
         // mask, online softmax per query tile, P fragments
-        uint4 pf[2][NPR][PLANES];  // [qt][pair][plane]
+        uint4 pf[NQT][NPR][PLANES];  // [qt][pair][plane]
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < NQT; ++qt) {
             float mt = -INFINITY;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
                     vf[pl] = *reinterpret_cast<uint4*>(&full);
                 }
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) {
+                for (int qt = 0; qt < NQT; ++qt) {
                     f32x4 a = o[qt][dt];
                     if constexpr (PLANES == 2) {
                         a = mma16<PLANES>(vf[1], pf[qt][pr][0], a);
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
 #pragma unroll
         for (int pr = 0; pr < NPR; ++pr)
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < NQT; ++qt) {
                 if constexpr (PLANES == 2) lacc[qt] = mma16<PLANES>(ones, pf[qt][pr][1], lacc[qt]);
                 lacc[qt] = mma16<PLANES>(ones, pf[qt][pr][0], lacc[qt]);
             }
@@ -316,11 +322,11 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
     tile(ntile - 1, std::true_type{});
 
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < NQT; ++qt) {
         const float l = lacc[qt][0];  // every row of the tile holds the sum for query column fr
         // split-f16: acc = sum (P * 2048) (V * 64); the output is written at the activation scale 64
         const float inv = l > 0.f ? 1.0f / l : 0.f;  // split-f16: P and its row sum both carry the factor 2048
-        const int q = q0 + wave * 32 + qt * 16 + fr;
+        const int q = q0 + wave * QW + qt * 16 + fr;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
             const f32x4 v = o[qt][dt] * inv;
@@ -329,10 +335,11 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(const char* __restrict__
     }
 }
 
-template <int PLANES, int KT16>
+template <int PLANES, int KT16, int NQT>
 int launch16(const void* qkv, void* out, const int32_t* lens, int B, int T, int H, const int32_t* row_start, hipStream_t s) {
     constexpr int LDS = 2 * 2 * KT16 * 128 * PLANES;
-    auto kern = attn16_kernel<PLANES, KT16>;
+    auto kern = attn16_kernel<PLANES, KT16, NQT>;
+    constexpr int QB16 = 64 * NQT;
     if (LDS > 48 * 1024) SWC_ENABLE_LDS(kern, LDS, "swc_attention16");
     dim3 grid((T + QB16 - 1) / QB16, H, B), block(256);
     hipLaunchKernelGGL(kern, grid, block, LDS, s, (const char*)qkv, (unsigned short*)out, lens, T, H, row_start);
@@ -349,9 +356,12 @@ extern "C" int swc_attention16(const void* qkv, void* out, const int32_t* lens, 
     SWC_CHECK_ARG(dtype == SWC_BF16 || dtype == SWC_F16S, "swc_attention16: dtype must be BF16 or F16S");
     SWC_CHECK_ARG(aligned16(qkv) && aligned16(out), "swc_attention16: unaligned");
     if (B == 0 || T == 0) return SWC_OK;
-    // 128-key tiles for the bf16 kernel (half the fences per key, occupancy 3 -> 2) measured the same within 2 %
-    int rc = dtype == SWC_BF16 ? launch16<1, 64>(qkv, out, lens, B, T, H, row_start, (hipStream_t)stream)
-                               : launch16<2, 64>(qkv, out, lens, B, T, H, row_start, (hipStream_t)stream);
+    // Measured alternatives for the bf16 kernel (tools/bench_attention.py, T = 500): 128-key tiles (half the fences per key,
+    // occupancy 3 -> 2) 56.2 us against 54.9; 16 queries per wave (91 registers, occupancy 5, but every K / V fragment
+    // feeds half the MFMAs) 70.5 us against 56.0.  PMC (tools/pmc_attention.sh): the SIMDs spend 58 % of their cycles
+    // issuing (VALU 46 %), matrix pipe 22 % busy, no LDS bank conflict: the kernel is bound by instructions per score.
+    int rc = dtype == SWC_BF16 ? launch16<1, 64, 2>(qkv, out, lens, B, T, H, row_start, (hipStream_t)stream)
+                               : launch16<2, 64, 2>(qkv, out, lens, B, T, H, row_start, (hipStream_t)stream);
     if (rc != SWC_OK) return rc;
     SWC_CHECK_LAUNCH("swc_attention16");
     return SWC_OK;
