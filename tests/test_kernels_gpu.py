@@ -97,6 +97,28 @@ def test_gemm_epilogue(dtype):
     assert _rel(r, A.double() @ W.double().T + res.double()) < (3e-6 if dtype == torch.float32 else 3e-5)
 
 
+def test_gemm_f32_epilogue_paths_agree():
+    """f32 outputs take the LDS-transposed epilogue when bias / gamma / residual / C are 16-byte aligned and the wave's
+    64-column slab lies inside N, the direct one otherwise: same arithmetic, bit-identical results (M tail, in-place residual)."""
+    ops = _ops()
+    M, N, K = 1000, 768, 768
+    g = torch.Generator().manual_seed(11)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(N, K, generator=g) / 16).to(torch.bfloat16).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV)
+    pad = torch.randn(2 * N + 8, generator=g).to(DEV)
+    bias_al, gamma_al = pad[:N].clone(), pad[N:2 * N].clone()
+    bias_un, gamma_un = pad[1:N + 1], pad[N + 1:2 * N + 1]          # 4-byte aligned views: the direct path
+    bias_un.copy_(bias_al); gamma_un.copy_(gamma_al)
+    for act in (ops.ACT_NONE, ops.ACT_GELU):
+        a = ops.gemm(A, W, M, N, K, bias=bias_al, gamma=gamma_al, residual=res, act=act)
+        b = ops.gemm(A, W, M, N, K, bias=bias_un, gamma=gamma_un, residual=res, act=act)
+        assert torch.equal(a, b)
+        ref = A.double().cpu() @ W.double().cpu().T + bias_al.double().cpu()
+        ref = (F.gelu(ref) if act == ops.ACT_GELU else ref) * gamma_al.double().cpu() + res.double().cpu()
+        assert _rel(a, ref) < 3e-5
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,dil,pad,T", [(80, 96, 3, 1, 1, 1, 101), (64, 40, 3, 2, 1, 1, 100),
                                                           (32, 32, 7, 1, 3, 9, 77), (32, 48, 7, 1, 9, 27, 60),
                                                           (96, 64, 7, 1, 1, 3, 130)])
