@@ -16,7 +16,7 @@ Two measurements, each W warm-up steps then EXACTLY K timed steps bracketed by b
   independent_shards (second field) — every rank encodes + decodes its own 32 utterances; no data-path traffic at all.
 Rank 0 prints ONE JSON line, with
   roofline     — the dominant kernel family (by accumulated device time), timed live with events on the launching stream
-                 inside the timed steps (every 10th timed step, counting back from the last, carries the event pairs: ~0.8 ms each);
+                 inside the timed steps (every 20th timed step, counting back from the last, carries the event pairs: ~0.8 ms each);
                  achieved = algorithmic FLOPs of the sampled launches / their summed duration; peak = dense MFMA peak of
                  its dtype; traffic = HBM bytes per launch from the committed rocprofv3 --pmc passes, tagged with the commit
                  they were taken at (a stale value is visible as a different commit).
@@ -228,7 +228,7 @@ def main():
         """W warm-ups, then exactly K steps between two fences; returns (seconds MAX over ranks, per-step ms list)."""
         for _ in range(args.warmup):
             step()
-        sampled = set(range(args.steps - 1, -1, -10)) if timer is not None else set()  # event pairs around every launch cost ~0.8 ms per sampled step
+        sampled = set(range(args.steps - 1, -1, -20)) if timer is not None else set()  # event pairs around every launch cost ~0.8 ms per sampled step
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         fence()
         t0 = time.perf_counter()
