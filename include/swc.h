@@ -184,10 +184,15 @@ int swc_convnext_mlp(const void* y, const void* w_stream, const float* b1, const
  * per 128) and x_out written once.  NOT in place (x_out != x: tiles read halo rows of their neighbours, which a finished
  * neighbour would already have updated); the caller ping-pongs two buffers over the 24 blocks.  dw_w7: [7][C], taps do
  * not cross utterances (rows b * T + t).  Same geometry limits.
+ * t_limit (optional, device int32 [B]; ragged batches): frames t >= t_limit[b] of utterance b need not be computed — a
+ * 128-frame tile that lies wholly at or beyond the limits of the utterances it touches returns at once and leaves its rows
+ * of x_out undefined.  The caller's limit must cover what it keeps plus the receptive field of the remaining blocks
+ * (3 frames per block); no reference counterpart (the reference computes every padded frame, model.py:327-333).
  */
 int swc_convnext_block(const float* x, float* x_out, const float* dw_w7, const float* dw_bias, const float* ln_w,
                        const float* ln_b, float eps, const void* w_stream, const float* b1, const float* b2,
-                       const float* gamma, int32_t B, int32_t T, int32_t C, int32_t I, void* stream);
+                       const float* gamma, int32_t B, int32_t T, int32_t C, int32_t I, const int32_t* t_limit,
+                       void* stream);
 
 /*
  * ConvNeXt front half: depthwise Conv1d(k=7, pad=3, groups=C) + LayerNorm(eps)

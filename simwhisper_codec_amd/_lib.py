@@ -68,7 +68,7 @@ SIGNATURES = {
     "swc_pack_rows": [_P, _P, _P, _P, _I, _I, _L, _P],
     "swc_convnext_pack": [_P, _P, _P, _I, _I, _P],
     "swc_convnext_mlp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "swc_convnext_block": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "swc_convnext_block": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
 }
 PLAIN = {"swc_version": ([], C.c_int), "swc_last_error": ([], C.c_char_p), "swc_device_count": ([], C.c_int),
          "swc_convnext_stream_bytes": ([_I, _I], C.c_int64)}

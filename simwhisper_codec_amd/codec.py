@@ -681,10 +681,12 @@ class AudioCodec(nn.Module):
         return self._mm(d1, P.d2w, B * Tv, P.vin, D, lda=D, ldw=3 * D, bias=P.d2b, taps=3, pad=2, t_in=Tv + 1, t_out=Tv,
                         out_dtype=dt).view(B, Tv, P.vin)
 
-    def _decode_latent(self, zq, lat_host, B, T, P, keep_frames=None):
+    def _decode_latent(self, zq, lat_host, B, T, P, keep_frames=None, ragged=False):
         """up-sampler + decoder + Vocos on zq [B, T, lat] f32 (already masked). Returns wav [B, T*1280] f32, or
         [B, keep_frames*160] when only the first keep_frames Vocos frames are wanted (long-form windows keep 2000
-        of their 3000 frames: the local-receptive-field vocoder then runs on 2000 + halo frames)."""
+        of their 3000 frames: the local-receptive-field vocoder then runs on 2000 + halo frames).
+        ragged (decode() only): samples beyond a row's own length lat_i * 1280 are never looked at, so the ConvNeXt
+        blocks skip the 128-frame tiles that lie beyond lat_i * 8 + VOCOS_HALO_FRAMES frames of row i."""
         Tt = P.stack * T
         x = self._upsample(zq, B, T, P)
         mel = self._decoder(x, lat_host, B, Tt, P)
@@ -692,14 +694,22 @@ class AudioCodec(nn.Module):
         if keep_frames is not None and keep_frames < Tv:
             mel = mel[:, :keep_frames].contiguous()
             Tv = keep_frames
-        return self._vocos(mel, B, Tv, P)
+        limits = None
+        if ragged and self.ragged_vocos:
+            lim = [min(Tv, 2 * P.stack * v + self.VOCOS_HALO_FRAMES) if v > 0 else 0 for v in lat_host]
+            if sum(spec.cdiv(v, 128) for v in lim) < 0.9 * B * spec.cdiv(Tv, 128):  # worth a per-tile test in every block
+                limits = lim
+        return self._vocos(mel, B, Tv, P, limits)
 
-    def _vocos(self, mel, B, Tv, P):
+    ragged_vocos = True  # decode(): skip ConvNeXt tiles beyond a row's kept frames + halo (bit-identical kept samples)
+
+    def _vocos(self, mel, B, Tv, P, limits=None):
         with trace.stage("vocos"):
-            return self._vocos_impl(mel, B, Tv, P)
+            return self._vocos_impl(mel, B, Tv, P, limits)
 
-    def _vocos_impl(self, mel, B, Tv, P):
-        """Vocos backbone + ISTFT head (modules.py:1492-1504, 1229-1248, 1053-1082, 831-886). mel [B, Tv, 80]."""
+    def _vocos_impl(self, mel, B, Tv, P, limits=None):
+        """Vocos backbone + ISTFT head (modules.py:1492-1504, 1229-1248, 1053-1082, 831-886). mel [B, Tv, 80].
+        limits (host ints per row, or None): frames at or beyond limits[b] need not be right (ragged decode)."""
         dt, C, M = P.ddt, P.vdim, B * Tv
         x = self._mm(mel, P.emw, M, C, P.vin, lda=P.vin, ldw=7 * P.vin, bias=P.emb, taps=7, pad=3, t_in=Tv, t_out=Tv)
         x = ops.layernorm(x, P.vnorm[0], P.vnorm[1], 1e-6, B=B, t_in=Tv, C_=C)
@@ -707,13 +717,14 @@ class AudioCodec(nn.Module):
         # two-GEMM form, whose 128 x 128 tiles spread over more CUs
         fused = P.fused_mlp and M >= self.fused_mlp_min_rows
         x2 = torch.empty_like(x) if fused else None  # the fused block is not in place: two buffers alternate
-        split = self._vocos_split(B, Tv) if fused else None
+        lim_dev = self._dev_ints(limits, mel.device) if (fused and limits is not None) else None
+        split = self._vocos_split(B, Tv) if (fused and lim_dev is None) else None
         if split is not None:
             x = self._blocks_two_streams(x, x2, B, Tv, C, P, *split)
         else:
             for blk in P.blocks if fused else ():  # the whole block (depthwise conv + LayerNorm + MLP + residual) is one kernel
                 ops.convnext_block(x, x2, blk["dw"], blk["db"], blk["ln"][0], blk["ln"][1], 1e-6, blk["ws"], blk["b1"],
-                                   blk["b2"], blk["g"], B=B, T=Tv, C_=C, I=P.vint)
+                                   blk["b2"], blk["g"], B=B, T=Tv, C_=C, I=P.vint, t_limit=lim_dev)
                 x, x2 = x2, x
         for blk in P.blocks:
             if fused:
@@ -862,10 +873,11 @@ class AudioCodec(nn.Module):
 
     @_on_model_device
     @torch.inference_mode()
-    def inference_detokenize(self, codes, codes_lengths, _keep_samples=None):
+    def inference_detokenize(self, codes, codes_lengths, _keep_samples=None, _ragged=False):
         """model.py:212-242. codes (G, B, T) integer, codes_lengths (B,). Returns y (B, 1, T*1280), output_length.
         _keep_samples (internal, decode()): only the first _keep_samples samples of every row are needed; y is then
-        shorter than T*1280 but those samples are bit-identical."""
+        shorter than T*1280 but those samples are bit-identical.  _ragged (internal, decode()): samples of row i beyond
+        codes_lengths[i] * 1280 are never looked at (they may then differ from the padded computation)."""
         P = self._packed()
         G, B, T = codes.shape
         lat = [int(v) for v in (codes_lengths.tolist() if torch.is_tensor(codes_lengths) else codes_lengths)]
@@ -876,7 +888,7 @@ class AudioCodec(nn.Module):
         if _keep_samples is not None:
             hop = self.generator_params["vocos"]["hop_size"]
             kf = spec.cdiv(_keep_samples, hop) + self.VOCOS_HALO_FRAMES
-        wav = self._decode_latent(zq, lat, B, T, P, keep_frames=kf)
+        wav = self._decode_latent(zq, lat, B, T, P, keep_frames=kf, ragged=_ragged)
         return {"y": wav[:, None, :], "output_length": lat_dev.long() * self.decoder_upsample_rate}
 
     # long-form scheduling: windows of one call are independent rows, so several 30 s windows are batched into
@@ -1094,7 +1106,7 @@ class AudioCodec(nn.Module):
                 else:
                     cg = torch.cat([codes[:, :, s0:e0] for _, s0, e0, _ in grp], dim=1)
                     lens = [v for *_, cl in grp for v in cl]
-                y = self.inference_detokenize(cg, lens, _keep_samples=keep if self.trim_vocos else None)["y"]
+                y = self.inference_detokenize(cg, lens, _keep_samples=keep if self.trim_vocos else None, _ragged=True)["y"]
                 # samples beyond an utterance's valid length fall after its final trim (n_i * 1280), so the
                 # zero-fill of model.py:356-360 is unobservable: keep the first `keep` samples of each window
                 for k, wdw in enumerate(grp):

@@ -94,6 +94,7 @@ struct CxFront {
     const float* ln_b;  // [C]
     int T;              // frames per utterance: rows b * T + t; taps do not cross utterances (zero padding)
     float eps;
+    const int* t_limit;  // optional [B]: frames t >= t_limit[b] of utterance b need not be computed (tiles wholly beyond are skipped)
 };
 
 // wstream: per wave w (4 of them) NS * 64 + CX_PF fragments of 1 KiB in the order of consumption (swc_convnext_pack)
@@ -111,6 +112,19 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lf = lane & 31, lh = lane >> 5;
     const int row0 = blockIdx.x * CX_BM;
+    if constexpr (FUSED_DW) {
+        // Ragged batches: a tile whose frames all lie at or beyond their utterances' limits does nothing (its rows of x_out
+        // stay undefined: the caller's limits include the receptive field of everything it keeps).  Block-uniform.
+        if (fr.t_limit) {
+            const int last = (row0 + CX_BM - 1 < M ? row0 + CX_BM - 1 : M - 1);
+            bool need = false;
+            for (int b = row0 / fr.T; b <= last / fr.T; ++b) {
+                const int t_lo = (row0 > b * fr.T ? row0 : b * fr.T) - b * fr.T;
+                need = need || t_lo < fr.t_limit[b];
+            }
+            if (!need) return;
+        }
+    }
 
     // ---- y tile -> LDS as B fragments: fragment (s, fb) = k-step s (16 channels) x frame block fb (32 frames) at
     // [(4 s + fb)][lane][16 B]; lane l supplies frame 32 fb + (l & 31), channels 16 s + 8 (l >> 5) .. + 7.  LDS-DMA with a
@@ -543,7 +557,8 @@ extern "C" int swc_convnext_mlp(const void* y, const void* w_stream, const float
 
 extern "C" int swc_convnext_block(const float* x, float* x_out, const float* dw_w7, const float* dw_bias, const float* ln_w,
                                   const float* ln_b, float eps, const void* w_stream, const float* b1, const float* b2,
-                                  const float* gamma, int32_t B, int32_t T, int32_t C, int32_t I, void* stream) {
+                                  const float* gamma, int32_t B, int32_t T, int32_t C, int32_t I, const int32_t* t_limit,
+                                  void* stream) {
     SWC_CHECK_ARG(x && x_out && x != x_out, "swc_convnext_block: x and x_out must be two different buffers");
     SWC_CHECK_ARG(x && dw_w7 && dw_bias && ln_w && ln_b && w_stream && b1 && b2 && gamma, "swc_convnext_block: null pointer");
     SWC_CHECK_ARG(C == CX_C && I > 0 && I % CX_SL == 0, "swc_convnext_block: needs C = %d and I a multiple of %d (C=%d I=%d)",
@@ -557,7 +572,7 @@ extern "C" int swc_convnext_block(const float* x, float* x_out, const float* dw_
     auto kern = convnext_mlp_kernel<true>;
     SWC_ENABLE_LDS(kern, CX_LDS, "swc_convnext_block");
     const unsigned grid = (unsigned)((M + CX_BM - 1) / CX_BM);
-    CxFront fr{dw_w7, dw_bias, ln_w, ln_b, T, eps};
+    CxFront fr{dw_w7, dw_bias, ln_w, ln_b, T, eps, t_limit};
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CX_LDS, (hipStream_t)stream, (const bf16_t*)nullptr,
                        (const u32x4*)w_stream, b1, b2, gamma, x, x_out, M, I / CX_SL, fr);
     SWC_CHECK_LAUNCH("swc_convnext_block");

@@ -319,8 +319,10 @@ def abi_version():
     return int(_lib.load().swc_version())
 
 
-def convnext_block(x, x_out, w7, dw_bias, ln_w, ln_b, eps, w_stream, b1, b2, gamma, *, B, T, C_, I, chip_share=1.0):
+def convnext_block(x, x_out, w7, dw_bias, ln_w, ln_b, eps, w_stream, b1, b2, gamma, *, B, T, C_, I, chip_share=1.0,
+                   t_limit=None):
     """One whole ConvNeXt block: residual stream x [B, T, C] f32 -> x_out (a different buffer; swc_convnext_block).
+    t_limit (int32 device tensor [B], ragged batches): frames at or beyond t_limit[b] need not be computed.
     chip_share (profiling only): the fraction of the chip this launch runs on when another chain runs beside it on a
     second stream; the timing hook charges duration x chip_share, so that TFLOP/s stays a whole-chip rate."""
     lib = _lib.load()
@@ -329,7 +331,7 @@ def convnext_block(x, x_out, w7, dw_bias, ln_w, ln_b, eps, w_stream, b1, b2, gam
     if prof is not None:
         prof.begin("convnext_bf16", 4.0 * B * T * C_ * I, chip_share)
     _lib.check(lib.swc_convnext_block(_ptr(x), _ptr(x_out), _ptr(w7), _ptr(dw_bias), _ptr(ln_w), _ptr(ln_b), eps, _ptr(w_stream),
-                                      _ptr(b1), _ptr(b2), _ptr(gamma), B, T, C_, I, _stream()), "swc_convnext_block")
+                                      _ptr(b1), _ptr(b2), _ptr(gamma), B, T, C_, I, _ptr(t_limit), _stream()), "swc_convnext_block")
     if prof is not None:
         prof.end()
     return x_out

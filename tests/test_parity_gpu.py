@@ -397,3 +397,31 @@ def test_valid_token_packing_is_exact(tag, precision):
         want = oracle(tag).encode([w.cpu() for w in wavs], trim=True)["codes_list"]
         for a, b in zip(c1, want):
             assert torch.equal(a.cpu().long(), b.long())
+
+@pytest.mark.parametrize("precision", ["mixed", "bf16"])
+def test_ragged_vocos_tile_skipping_is_exact(precision):
+    """decode() of a ragged batch: the ConvNeXt blocks skip the 128-frame tiles beyond a row's kept frames + halo
+    (swc_convnext_block t_limit).  Every returned sample is bit-identical to the run that computes all padded frames."""
+    from simwhisper_codec_amd import ops, synth
+    m = model("real", precision)
+    secs = [27.0, 2.2, 11.3, 0.7, 19.9, 6.1, 24.5, 3.3, 14.0, 1.0]   # 10 rows x 2700 frames: the fused block kernel is used
+    wavs = [synth.synth_audio(int(16000 * t) + 31 * i, index=1200 + i, kind="speech" if i % 2 else "noise").to(DEV)
+            for i, t in enumerate(secs)]
+    codes = m.encode(wavs)["codes_list"]
+    keep = m.ragged_vocos
+    seen = []
+    real = ops.convnext_block
+    ops.convnext_block = lambda *a, **k: (seen.append(k.get("t_limit") is not None), real(*a, **k))[1]
+    try:
+        m.ragged_vocos = False
+        w0 = m.decode(codes)["syn_wav_list"]
+        n0 = len(seen)
+        m.ragged_vocos = True
+        w1 = m.decode(codes)["syn_wav_list"]
+    finally:
+        ops.convnext_block = real
+        m.ragged_vocos = keep
+    assert n0 > 0 and not any(seen[:n0]) and all(seen[n0:]) and len(seen) == 2 * n0   # fused blocks ran, with limits the second time
+    for a, b in zip(w0, w1):
+        assert a.shape == b.shape and torch.isfinite(b).all() and torch.equal(a, b)
+
