@@ -72,6 +72,21 @@ __device__ __forceinline__ void f16s_store4(unsigned short* row, long k, float a
     *reinterpret_cast<uint2*>(p + 32) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
 }
 
+// two values at once -> one dword of hi halves, one of lo halves: the conversions are the packed forms (one
+// v_cvt_pk_f16_f32 per pair, RNE like the scalar casts), the clamp one v_med3 each, the range tracking one v_max3 for both.
+// Bit-identical to two f16s_split calls.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void f16s_split2(float a, float b, unsigned& hi2, unsigned& lo2, float& amax) {
+    amax = fmaxf(fmaxf(amax, fabsf(a)), fabsf(b));
+    a = __builtin_amdgcn_fmed3f(a, -SWC_F16S_LIMIT, SWC_F16S_LIMIT);
+    b = __builtin_amdgcn_fmed3f(b, -SWC_F16S_LIMIT, SWC_F16S_LIMIT);
+    const f16x2_t h = __builtin_convertvector((f32x2_t){a, b}, f16x2_t);
+    const f16x2_t l = __builtin_convertvector((f32x2_t){a - (float)h[0], b - (float)h[1]}, f16x2_t);
+    hi2 = *reinterpret_cast<const unsigned*>(&h);
+    lo2 = *reinterpret_cast<const unsigned*>(&l);
+}
+
 // the same with range tracking
 __device__ __forceinline__ void f16s_split(float v, unsigned short& hi, unsigned short& lo, float& amax) {
     amax = fmaxf(amax, fabsf(v));

@@ -224,19 +224,14 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmP& p, f32x4 (&acc
                     }
                 }
                 unsigned short* rowp = reinterpret_cast<unsigned short*>(p.C) + (long)row * p.ldc * 2;
-                unsigned short h[16], l[16];
+                unsigned h2[8], l2[8];
 #pragma unroll
-                for (int c = 0; c < 16; ++c) f16s_split(v[c] * p.out_scale, h[c], l[c], amax);
+                for (int c = 0; c < 8; ++c) f16s_split2(v[2 * c] * p.out_scale, v[2 * c + 1] * p.out_scale, h2[c], l2[c], amax);
                 unsigned short* hp = rowp + f16s_col(col0);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    uint4 uh, ul;
-                    uh.x = h[8 * q + 0] | ((unsigned)h[8 * q + 1] << 16); uh.y = h[8 * q + 2] | ((unsigned)h[8 * q + 3] << 16);
-                    uh.z = h[8 * q + 4] | ((unsigned)h[8 * q + 5] << 16); uh.w = h[8 * q + 6] | ((unsigned)h[8 * q + 7] << 16);
-                    ul.x = l[8 * q + 0] | ((unsigned)l[8 * q + 1] << 16); ul.y = l[8 * q + 2] | ((unsigned)l[8 * q + 3] << 16);
-                    ul.z = l[8 * q + 4] | ((unsigned)l[8 * q + 5] << 16); ul.w = l[8 * q + 6] | ((unsigned)l[8 * q + 7] << 16);
-                    reinterpret_cast<uint4*>(hp)[q] = uh;
-                    reinterpret_cast<uint4*>(hp + 32)[q] = ul;
+                    reinterpret_cast<uint4*>(hp)[q] = make_uint4(h2[4 * q], h2[4 * q + 1], h2[4 * q + 2], h2[4 * q + 3]);
+                    reinterpret_cast<uint4*>(hp + 32)[q] = make_uint4(l2[4 * q], l2[4 * q + 1], l2[4 * q + 2], l2[4 * q + 3]);
                 }
             }
         } else if (vec_ok) {
