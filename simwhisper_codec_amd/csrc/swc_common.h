@@ -63,15 +63,6 @@ __device__ __forceinline__ void f16s_split(float v, unsigned short& hi, unsigned
 }
 // half index of logical column k inside a split row (block of 32: 32 hi then 32 lo)
 __device__ __forceinline__ long f16s_col(long k) { return (k >> 5) * 64 + (k & 31); }
-// store 4 consecutive logical columns k..k+3 (k % 4 == 0) of a split row starting at `row` (halves)
-__device__ __forceinline__ void f16s_store4(unsigned short* row, long k, float a, float b, float c, float d) {
-    unsigned short h[4], l[4];
-    f16s_split(a, h[0], l[0]); f16s_split(b, h[1], l[1]); f16s_split(c, h[2], l[2]); f16s_split(d, h[3], l[3]);
-    unsigned short* p = row + f16s_col(k);
-    *reinterpret_cast<uint2*>(p) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
-    *reinterpret_cast<uint2*>(p + 32) = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
-}
-
 // two values at once -> one dword of hi halves, one of lo halves: the conversions are the packed forms (one
 // v_cvt_pk_f16_f32 per pair, RNE like the scalar casts), the clamp one v_med3 each, the range tracking one v_max3 for both.
 // Bit-identical to two f16s_split calls.
@@ -87,14 +78,24 @@ __device__ __forceinline__ void f16s_split2(float a, float b, unsigned& hi2, uns
     lo2 = *reinterpret_cast<const unsigned*>(&l);
 }
 
+// store 4 consecutive logical columns k..k+3 (k % 4 == 0) of a split row starting at `row` (halves)
+__device__ __forceinline__ void f16s_store4(unsigned short* row, long k, float a, float b, float c, float d, float& amax) {
+    unsigned h0, l0, h1, l1;
+    f16s_split2(a, b, h0, l0, amax);
+    f16s_split2(c, d, h1, l1, amax);
+    unsigned short* p = row + f16s_col(k);
+    *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(p + 32) = make_uint2(l0, l1);
+}
+__device__ __forceinline__ void f16s_store4(unsigned short* row, long k, float a, float b, float c, float d) {
+    float unused = 0.f;
+    f16s_store4(row, k, a, b, c, d, unused);
+}
+
 // the same with range tracking
 __device__ __forceinline__ void f16s_split(float v, unsigned short& hi, unsigned short& lo, float& amax) {
     amax = fmaxf(amax, fabsf(v));
     f16s_split(v, hi, lo);
-}
-__device__ __forceinline__ void f16s_store4(unsigned short* row, long k, float a, float b, float c, float d, float& amax) {
-    amax = fmaxf(fmaxf(amax, fabsf(a)), fmaxf(fmaxf(fabsf(b), fabsf(c)), fabsf(d)));
-    f16s_store4(row, k, a, b, c, d);
 }
 
 // 4 floats -> 4 e4m3 bytes (v_cvt_pk_fp8_f32, RNE), saturating at the largest finite value
