@@ -177,8 +177,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const void* __restrict__ q
                             v[2] * SWC_F16S_ACT_SCALE, v[3] * SWC_F16S_ACT_SCALE);
             } else if constexpr (BF16) {
                 uint2 u;
-                u.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                u.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                u.x = bf16_pack2(v[0], v[1]);
+                u.y = bf16_pack2(v[2], v[3]);
                 *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(out) + orow + dt * 16 + fh * 4) = u;
             } else {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + orow + dt * 16 + fh * 4) =

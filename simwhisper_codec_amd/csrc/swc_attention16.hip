@@ -97,8 +97,8 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
         if (q >= qlim) return;
         if constexpr (PLANES == 1) {
             uint2 u;
-            u.x = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(bq) << 16);
-            u.y = (unsigned)f32_to_bf16(c) | ((unsigned)f32_to_bf16(e) << 16);
+            u.x = bf16_pack2(a, bq);
+            u.y = bf16_pack2(c, e);
             *reinterpret_cast<uint2*>(out + (r0 + q) * D + head * 64 + d) = u;
         } else {
             f16s_store4(out + (r0 + q) * 2L * D, head * 64 + d, a, bq, c, e);

@@ -39,6 +39,15 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float x) {
     __hip_bfloat16 h = __float2bfloat16(x);
     return *reinterpret_cast<bf16_t*>(&h);
 }
+// two f32 -> one dword (lo in bits 0..15, hi in 16..31), RNE: ONE v_cvt_pk_bf16_f32 (the `cast | cast << 16` form compiles
+// to one conversion per value plus the merge).  A vector conversion, not inline asm: hipcc then still inserts the wait
+// state a transcendental result needs before its first use.
+typedef float f32x2_c __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_c __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_pack2(float lo, float hi) {
+    const bf16x2_c r = __builtin_convertvector((f32x2_c){lo, hi}, bf16x2_c);
+    return *reinterpret_cast<const unsigned*>(&r);
+}
 __device__ __forceinline__ float bf16_to_f32(bf16_t x) {
     return __uint_as_float(((unsigned)x) << 16);
 }

@@ -165,8 +165,8 @@ __device__ __forceinline__ void gemm_epilogue_slab(const GemmP& p, f32x4 (&acc)[
                 *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.C) + (long)row * p.ldc + col) = fp8_pack4(v0 * os, v1 * os, v2 * os, v3 * os, amax);
             } else {
                 uint2 u;
-                u.x = (unsigned)f32_to_bf16(v0) | ((unsigned)f32_to_bf16(v1) << 16);
-                u.y = (unsigned)f32_to_bf16(v2) | ((unsigned)f32_to_bf16(v3) << 16);
+                u.x = bf16_pack2(v0, v1);
+                u.y = bf16_pack2(v2, v3);
                 *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (long)row * p.ldc + col) = u;
             }
         }
@@ -260,10 +260,10 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmP& p, f32x4 (&acc
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     uint4 u;
-                    u.x = (unsigned)f32_to_bf16(v[8 * j + 0]) | ((unsigned)f32_to_bf16(v[8 * j + 1]) << 16);
-                    u.y = (unsigned)f32_to_bf16(v[8 * j + 2]) | ((unsigned)f32_to_bf16(v[8 * j + 3]) << 16);
-                    u.z = (unsigned)f32_to_bf16(v[8 * j + 4]) | ((unsigned)f32_to_bf16(v[8 * j + 5]) << 16);
-                    u.w = (unsigned)f32_to_bf16(v[8 * j + 6]) | ((unsigned)f32_to_bf16(v[8 * j + 7]) << 16);
+                    u.x = bf16_pack2(v[8 * j + 0], v[8 * j + 1]);
+                    u.y = bf16_pack2(v[8 * j + 2], v[8 * j + 3]);
+                    u.z = bf16_pack2(v[8 * j + 4], v[8 * j + 5]);
+                    u.w = bf16_pack2(v[8 * j + 6], v[8 * j + 7]);
                     reinterpret_cast<uint4*>(cp)[j] = u;
                 }
             }

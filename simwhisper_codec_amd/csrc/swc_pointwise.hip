@@ -15,8 +15,8 @@ __device__ __forceinline__ void store4<float>(float* p, float a, float b, float 
 template <>
 __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, float a, float b, float c, float d) {
     uint2 u;
-    u.x = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
-    u.y = (unsigned)f32_to_bf16(c) | ((unsigned)f32_to_bf16(d) << 16);
+    u.x = bf16_pack2(a, b);
+    u.y = bf16_pack2(c, d);
     *reinterpret_cast<uint2*>(p) = u;
 }
 
