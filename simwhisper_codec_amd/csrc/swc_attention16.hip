@@ -152,8 +152,13 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
         }
     };
     auto fence = [&]() {
+#if defined(ATT_ABL) && (ATT_ABL & 1)   // timing ablation only (wrong results): no workgroup barrier per key tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif defined(ATT_ABL) && (ATT_ABL & 2)  // timing ablation only: neither the DMA wait nor the barrier
+#else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#endif
     };
 
     f32x4 o[NQT][4];
