@@ -71,6 +71,27 @@ def build_library(force=False, verbose=False):
     return LIB_PATH
 
 
+IO_LIB_PATH = os.path.join(HERE, "libswc_io.so")
+IO_SOURCES = ["swc_flac.c"]
+
+
+def build_io_library(force=False):
+    """Host-side helper library (plain C, gcc): the FLAC decoder behind wavio.load_audio.  No GPU code, no dependency."""
+    srcs = [os.path.join(CSRC, f) for f in IO_SOURCES]
+    if not force and os.path.exists(IO_LIB_PATH) and all(os.path.getmtime(f) <= os.path.getmtime(IO_LIB_PATH) for f in srcs):
+        return IO_LIB_PATH
+    cc = next((c for c in (os.environ.get("CC"), shutil.which("gcc"), shutil.which("cc"), shutil.which("clang")) if c), None)
+    if cc is None:
+        raise RuntimeError("no C compiler found for libswc_io.so (set CC)")
+    tmp = IO_LIB_PATH + ".tmp"
+    r = subprocess.run([cc, "-O2", "-std=c99", "-Wall", "-shared", "-fPIC", "-o", tmp] + srcs,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"building libswc_io.so failed:\n{r.stdout}")
+    os.replace(tmp, IO_LIB_PATH)
+    return IO_LIB_PATH
+
+
 def stamp_commit():
     """The GPU box receives a snapshot without .git: leave the commit the library was built from next to it, so that
     bench.py / profile summaries taken there can name it (the file is git-ignored and travels with the .so)."""
@@ -89,3 +110,4 @@ def stamp_commit():
 if __name__ == "__main__":
     path = build_library(force="--force" in sys.argv, verbose="-v" in sys.argv)
     print(path)
+    print(build_io_library(force="--force" in sys.argv))

@@ -1,12 +1,15 @@
 """Audio file IO around the hot path (the role of utils/helpers.py:77-111 in the reference).
 
 torchaudio is not available offline, so this is a small self-contained RIFF/WAVE reader
-and writer (stdlib + numpy): PCM 8/16/24/32-bit and IEEE float 32/64 in, PCM16 out.
+and writer (stdlib + numpy): PCM 8/16/24/32-bit and IEEE float 32/64 in, PCM16 out — and a native FLAC decoder
+(csrc/swc_flac.c -> libswc_io.so, plain C through ctypes; LibriSpeech, the codec's evaluation corpus, is FLAC).
 Conventions the reference leaves to torchaudio and which are therefore OUR choice:
   * multi-channel input is averaged to mono (helpers.py:82-83 does the same);
   * sample-rate conversion: polyphase Kaiser-windowed sinc (scipy.signal.resample_poly);
-  * float -> PCM16: round(clip(x, -1, 1) * 32767).
-`.flac` / `.mp3` are listed (helpers.py:106) but cannot be decoded here: a clear error is raised.
+  * float -> PCM16: round(clip(x, -1, 1) * 32767);
+  * FLAC integers are scaled by 2^-(bits-1), as torchaudio does; every decode checks both frame CRCs and the stream's
+    MD5 signature and raises on a mismatch (no other FLAC decoder exists here to pin this one against).
+`.mp3` is listed (helpers.py:106) but cannot be decoded here: a clear error is raised.
 """
 import glob
 import logging
@@ -70,12 +73,64 @@ def _read_wav(path):
     return x[: n * ch].reshape(n, ch), sr
 
 
+_FLAC_ERRORS = {-1: "not a FLAC stream or malformed", -2: "a frame failed its CRC", -3: "uses a reserved / unsupported coding",
+                -4: "output buffer too small", -5: "decoded audio does not match the stream's MD5 signature"}
+_io_lib = None
+
+
+def _io():
+    """libswc_io.so (built on demand with the host C compiler)."""
+    global _io_lib
+    if _io_lib is None:
+        import ctypes as C
+        from . import build
+        lib = C.CDLL(build.build_io_library())
+        lib.swc_flac_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int64)]
+        lib.swc_flac_info.restype = C.c_int
+        lib.swc_flac_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
+        lib.swc_flac_decode.restype = C.c_int64
+        lib.swc_flac_max_samples.argtypes = [C.c_size_t]
+        lib.swc_flac_max_samples.restype = C.c_int64
+        _io_lib = lib
+    return _io_lib
+
+
+def _read_flac(path):
+    """-> (float32 array (n, channels) in [-1, 1), sample rate).  Raises ValueError on anything that does not verify."""
+    import ctypes as C
+    with open(path, "rb") as f:
+        data = f.read()
+    lib = _io()
+    sr, ch, bits, total = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+    rc = lib.swc_flac_info(data, len(data), C.byref(sr), C.byref(ch), C.byref(bits), C.byref(total))
+    if rc != 0:
+        raise ValueError(f"{path}: {_FLAC_ERRORS.get(rc, rc)}")
+    cap = int(total.value) or int(lib.swc_flac_max_samples(len(data)))
+    md5 = C.c_int32(0)
+    while True:
+        out = np.empty((cap, ch.value), dtype=np.int32)
+        n = lib.swc_flac_decode(data, len(data), out.ctypes.data_as(C.c_void_p), cap, C.byref(md5))
+        if n == -4 and not total.value and cap < (1 << 31):  # length unknown: grow
+            cap *= 4
+            continue
+        break
+    if n < 0:
+        raise ValueError(f"{path}: {_FLAC_ERRORS.get(int(n), int(n))}")
+    if not md5.value:
+        logging.warning(f"{path}: the stream carries no MD5 signature; frame CRCs verified only")
+    return out[:n].astype(np.float32) / np.float32(1 << (bits.value - 1)), int(sr.value)
+
+
 def load_audio(audio_path, target_sample_rate):
     """-> FloatTensor (1, 1, T) at target_sample_rate, mono (helpers.py:77-94)."""
     ext = os.path.splitext(audio_path)[1].lower()
-    if ext != ".wav":
-        raise RuntimeError(f"{audio_path}: only .wav can be decoded offline (no torchaudio / codec libraries here)")
-    x, sr = _read_wav(audio_path)
+    if ext == ".flac":
+        x, sr = _read_flac(audio_path)
+    elif ext == ".wav":
+        x, sr = _read_wav(audio_path)
+    else:
+        raise RuntimeError(f"{audio_path}: only .wav and .flac can be decoded offline (no torchaudio / codec libraries here)")
     x = x.mean(axis=1) if x.shape[1] > 1 else x[:, 0]
     if sr != target_sample_rate:
         from scipy.signal import resample_poly

@@ -1,0 +1,94 @@
+"""The native FLAC decoder (csrc/swc_flac.c, the input side of inference.py: LibriSpeech is FLAC) against streams written by
+tests/flac_encode.py.  Parity note: no FLAC library or tool exists in this environment (no torchaudio, soundfile, flac, ffmpeg),
+so decoder and test encoder are both written from the format description — parity with libFLAC is UNPINNED here; what pins
+real files at run time is the decoder's own verification of CRC-8, CRC-16 and the stream's MD5 signature (tested below)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import flac_encode as fe  # noqa: E402
+
+from simwhisper_codec_amd import wavio  # noqa: E402
+
+
+def _signal(n, ch, bps, seed):
+    g = np.random.default_rng(seed)
+    t = np.arange(n)[:, None]
+    amp = (1 << (bps - 1)) * 0.4
+    x = amp * (np.sin(2 * np.pi * (220.0 + 37 * np.arange(ch)) * t / 16000.0) * 0.6 + 0.1 * g.standard_normal((n, ch)))
+    if ch == 2:
+        x[:, 1] = 0.7 * x[:, 0] + 0.3 * x[:, 1]  # correlated channels: side signals stay small
+    return np.clip(np.round(x), -(1 << (bps - 1)), (1 << (bps - 1)) - 1).astype(np.int64)
+
+
+def _roundtrip(tmp_path, x, sr, bps, **kw):
+    p = tmp_path / "t.flac"
+    p.write_bytes(fe.encode(x, sr, bps, **kw))
+    got, got_sr = wavio._read_flac(str(p))
+    assert got_sr == sr and got.shape == x.shape
+    assert np.array_equal(np.round(got.astype(np.float64) * (1 << (bps - 1))).astype(np.int64), x)
+    return p
+
+
+@pytest.mark.parametrize("ch,bps", [(1, 16), (2, 16), (1, 24), (2, 24), (1, 8), (2, 12)])
+def test_flac_subframe_types_and_stereo_modes(tmp_path, ch, bps):
+    n = 5 * 1024 + 333
+    x = _signal(n, ch, bps, seed=ch * 100 + bps)
+    x[1024:2048] = x[1024]                      # a constant block
+    x[2048:3072] &= ~np.int64(7)                # three wasted bits in block 2
+    kinds = ["verbatim", "constant", ("fixed", 2), ("lpc", 8), ("fixed", 4), ("fixed", 0), ("lpc", 1), ("fixed", 1), ("lpc", 32), ("fixed", 3)]
+
+    def plan(fi, c):
+        if c is None:
+            return [0, 8, 9, 10][fi % 4]
+        return dict(kind=kinds[(fi + (c or 0)) % len(kinds)], porder=[0, 2, 3, 1][fi % 4], rice2=(bps > 16 or fi % 2 == 1),
+                    escape_part=(1 if fi % 3 == 2 else None), wasted=(3 if fi == 2 else 0))
+    _roundtrip(tmp_path, x, 16000, bps, blocksize=1024, plan=plan)
+
+
+@pytest.mark.parametrize("blocksize", [192, 256, 1000, 4096, 4608])
+def test_flac_block_sizes_and_short_last_block(tmp_path, blocksize):
+    x = _signal(3 * blocksize + 17, 1, 16, seed=blocksize)
+    _roundtrip(tmp_path, x, 22050, 16, blocksize=blocksize, plan=lambda fi, c: dict(kind=("lpc", 6), porder=0) if c is not None else 0)
+
+
+def test_flac_load_audio_mono_resample_and_id3(tmp_path):
+    x = _signal(16000, 2, 16, seed=5)
+    p = tmp_path / "a.flac"
+    p.write_bytes(fe.encode(x, 8000, 16, blocksize=4096, id3=True))
+    wav = wavio.load_audio(str(p), 16000)
+    assert wav.shape == (1, 1, 32000) and wav.dtype == torch.float32
+    # the same samples as a WAV file go through the same mono / resampling code: identical result
+    import struct
+    pcm = x.astype("<i2").tobytes()
+    (tmp_path / "a.wav").write_bytes(b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, 1, 2, 8000, 8000 * 4, 4, 16) + b"data" + struct.pack("<I", len(pcm)) + pcm)
+    assert torch.equal(wav, wavio.load_audio(str(tmp_path / "a.wav"), 16000))
+
+
+def test_flac_corruption_is_detected(tmp_path):
+    x = _signal(4096, 1, 16, seed=9)
+    good = fe.encode(x, 16000, 16, blocksize=1024)
+    p = tmp_path / "bad.flac"
+    # a flipped bit in a residual: the frame's CRC-16 no longer matches
+    bad = bytearray(good); bad[len(bad) // 2] ^= 0x10
+    p.write_bytes(bytes(bad))
+    with pytest.raises(ValueError):
+        wavio._read_flac(str(p))
+    # a stream whose frames are intact but whose MD5 signature belongs to other audio
+    other = bytearray(good); other[8 + 18] ^= 0xFF   # first byte of the MD5 field in STREAMINFO
+    p.write_bytes(bytes(other))
+    with pytest.raises(ValueError, match="MD5"):
+        wavio._read_flac(str(p))
+    # no signature (all zero): accepted on the CRCs alone
+    p.write_bytes(fe.encode(x, 16000, 16, blocksize=1024, md5=False))
+    got, _ = wavio._read_flac(str(p))
+    assert got.shape == (4096, 1)
+    # not FLAC at all
+    p.write_bytes(b"fLaC")
+    with pytest.raises(ValueError):
+        wavio._read_flac(str(p))

@@ -163,8 +163,11 @@ def test_wav_io_roundtrip(tmp_path):
     assert (z - 0.25 * x).abs().max() < 1e-6
     (tmp_path / "c.flac").write_bytes(b"fLaC")
     assert [os.path.basename(f) for f in find_audio_files(str(tmp_path))] == ["b.wav", "c.flac", "a.wav"]
-    with pytest.raises(RuntimeError):
+    with pytest.raises(ValueError):  # a FLAC marker and nothing else: the native decoder rejects it (tests/test_flac_cpu.py)
         load_audio(str(tmp_path / "c.flac"), 16000)
+    (tmp_path / "d.mp3").write_bytes(b"ID3")
+    with pytest.raises(RuntimeError):  # no MP3 decoder offline: a clear error
+        load_audio(str(tmp_path / "d.mp3"), 16000)
 
 
 def test_cli_flags_are_the_reference_flags():

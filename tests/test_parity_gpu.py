@@ -286,8 +286,16 @@ def test_cli_end_to_end(tmp_path):
     lens = {"a.wav": 16000, "b.wav": 5000, "c.wav": 40000}
     for i, (name, n) in enumerate(lens.items()):
         save_audio(str(ind / name), synth.synth_audio(n, index=80 + i, kind="speech").reshape(1, -1), 16000)
+    # the PCM16 samples of c.wav once more as a FLAC file (native decoder, csrc/swc_flac.c): same batch, same output bytes
+    import numpy as np
+    import flac_encode
+    from simwhisper_codec_amd.wavio import _read_wav
+    pcm = np.round(_read_wav(str(ind / "c.wav"))[0] * 32768.0).astype(np.int64)
+    (ind / "d.flac").write_bytes(flac_encode.encode(pcm, 16000, 16, blocksize=4096,
+                                                    plan=lambda fi, c: dict(kind=("lpc", 8), porder=2) if c is not None else 0))
     inference.main(["--config_path", str(cfg), "--synthetic_checkpoint", "--device", "cuda", "--batch_size", "2",
                     "--input_dir", str(tmp_path / "in"), "--output_dir", str(outd), "--precision", "mixed"])
+    assert (outd / "d.wav").read_bytes() == (outd / "c.wav").read_bytes()
     m = model("tiny", "mixed")
     for name, n in lens.items():
         y = load_audio(str(outd / name), 16000).reshape(-1)
