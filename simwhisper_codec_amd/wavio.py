@@ -5,7 +5,8 @@ and writer (stdlib + numpy): PCM 8/16/24/32-bit and IEEE float 32/64 in, PCM16 o
 (csrc/swc_flac.c -> libswc_io.so, plain C through ctypes; LibriSpeech, the codec's evaluation corpus, is FLAC).
 Conventions the reference leaves to torchaudio and which are therefore OUR choice:
   * multi-channel input is averaged to mono (helpers.py:82-83 does the same);
-  * sample-rate conversion: polyphase Kaiser-windowed sinc (scipy.signal.resample_poly);
+  * sample-rate conversion: `resample` below, the sinc / Hann-window algorithm torchaudio.functional.resample documents
+    (its defaults), restated — bit-parity with torchaudio itself is unpinned here;
   * float -> PCM16: round(clip(x, -1, 1) * 32767);
   * FLAC integers are scaled by 2^-(bits-1), as torchaudio does; every decode checks both frame CRCs and the stream's
     MD5 signature and raises on a mismatch (no other FLAC decoder exists here to pin this one against).
@@ -132,11 +133,37 @@ def load_audio(audio_path, target_sample_rate):
     else:
         raise RuntimeError(f"{audio_path}: only .wav and .flac can be decoded offline (no torchaudio / codec libraries here)")
     x = x.mean(axis=1) if x.shape[1] > 1 else x[:, 0]
+    wav = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
     if sr != target_sample_rate:
-        from scipy.signal import resample_poly
-        g = gcd(int(sr), int(target_sample_rate))
-        x = resample_poly(x.astype(np.float64), target_sample_rate // g, sr // g).astype(np.float32)
-    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).reshape(1, 1, -1)
+        wav = resample(wav, int(sr), int(target_sample_rate))
+    return wav.reshape(1, 1, -1)
+
+
+def resample(wav, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """Band-limited sinc interpolation with a Hann window: the algorithm torchaudio.functional.resample documents and uses
+    with its defaults (`sinc_interp_hann`, lowpass_filter_width 6, rolloff 0.99), which is what helpers.py:86 calls.
+    Restated from that published algorithm — torchaudio is absent here, so bit-parity with it is unpinned: kernel of
+    new/gcd phases x (2 width + orig/gcd) taps built in float64, float32 convolution with stride orig/gcd over the signal
+    padded by (width, width + orig/gcd), output length ceil(new * n / orig).  wav: 1-D float32 tensor."""
+    import math
+    g = gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    if orig == new:
+        return wav
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx
+    t = (t * base).clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernel = torch.where(t == 0, torch.ones_like(t), t.sin() / t) * window * (base / orig)
+    kernel = kernel.to(torch.float32)                                   # [new, 1, 2 width + orig]
+    n = wav.shape[-1]
+    padded = torch.nn.functional.pad(wav.reshape(1, 1, -1).to(torch.float32), (width, width + orig))
+    out = torch.nn.functional.conv1d(padded, kernel, stride=orig)       # [1, new, frames]
+    out = out.transpose(1, 2).reshape(-1)
+    return out[: int(math.ceil(new * n / orig))].contiguous()
 
 
 def save_audio(audio_outpath, audio_out, sample_rate):

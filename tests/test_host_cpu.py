@@ -170,6 +170,21 @@ def test_wav_io_roundtrip(tmp_path):
         load_audio(str(tmp_path / "d.mp3"), 16000)
 
 
+@pytest.mark.parametrize("orig,new", [(8000, 16000), (44100, 16000), (48000, 16000), (22050, 16000)])
+def test_resample_is_band_limited_interpolation(orig, new):
+    """wavio.resample (torchaudio's documented sinc_interp_hann algorithm, width 6, rolloff 0.99): output length
+    ceil(new * n / orig), a 440 Hz tone comes back as the same tone (pass-band ripple of that window: < 1e-3)."""
+    import math
+    from simwhisper_codec_amd.wavio import resample
+    n = orig + 123
+    x = torch.sin(2 * math.pi * 440.0 * torch.arange(n) / orig).float()
+    y = resample(x, orig, new)
+    assert y.dtype == torch.float32 and y.shape[0] == math.ceil(new * n / orig)
+    ref = torch.sin(2 * math.pi * 440.0 * torch.arange(y.shape[0]) / new)
+    assert (y - ref)[300:-300].abs().max().item() < 1e-3
+    assert resample(x, orig, orig) is x
+
+
 def test_cli_flags_are_the_reference_flags():
     import inference
     p = inference.build_parser()
