@@ -62,7 +62,7 @@ static uint32_t br_unary(br_t* b) { /* number of 0 bits before the next 1 bit */
         int z = __builtin_clzll(b->acc);
         if (z >= b->bits) { q += (uint32_t)b->bits; b->acc = 0; b->bits = 0; continue; }
         q += (uint32_t)z;
-        b->acc <<= (z + 1);
+        b->acc = z == 63 ? 0 : b->acc << (z + 1);
         b->bits -= z + 1;
         return q;
     }
@@ -209,8 +209,8 @@ static int read_residual(br_t* b, int64_t* out, int bs, int order) {
             for (int i = 0; i < cnt; ++i) out[idx++] = br_read_signed(b, raw);
         } else {
             for (int i = 0; i < cnt; ++i) {
-                uint32_t q = br_unary(b);
-                uint32_t u = (q << k) | br_read(b, k);
+                uint64_t q = br_unary(b);
+                uint64_t u = (q << k) | br_read(b, k);   /* 32-bit audio: folded residuals need more than 32 bits */
                 out[idx++] = (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
             }
         }
@@ -254,7 +254,7 @@ static int read_subframe(br_t* b, int64_t* s, int bs, int bps) {
                 case 4: p = 4 * s[i - 1] - 6 * s[i - 2] + 4 * s[i - 3] - s[i - 4]; break;
                 default: break;
             }
-            s[i] += p;
+            s[i] = (int64_t)((uint64_t)s[i] + (uint64_t)p);
         }
     } else if (type >= 32) { /* LPC, order (type & 31) + 1 */
         int order = (type & 31) + 1;
@@ -272,15 +272,15 @@ static int read_subframe(br_t* b, int64_t* s, int bs, int bps) {
         rc = read_residual(b, s, bs, order);
         if (rc != FLAC_OK) return rc;
         for (int i = order; i < bs; ++i) {
-            int64_t p = 0;
-            for (int j = 0; j < order; ++j) p += (int64_t)coef[j] * s[i - 1 - j];
-            s[i] += p >> shift;
+            uint64_t p = 0;   /* wraps on damaged streams instead of overflowing; exact on valid ones (|sum| < 2^53) */
+            for (int j = 0; j < order; ++j) p += (uint64_t)(int64_t)coef[j] * (uint64_t)s[i - 1 - j];
+            s[i] = (int64_t)((uint64_t)s[i] + (uint64_t)((int64_t)p >> shift));
         }
     } else {
         return FLAC_E_UNSUP; /* reserved subframe types */
     }
     if (b->err) return FLAC_E_FORMAT;
-    if (wasted) for (int i = 0; i < bs; ++i) s[i] *= ((int64_t)1 << wasted);
+    if (wasted) for (int i = 0; i < bs; ++i) s[i] = (int64_t)((uint64_t)s[i] << wasted);
     return FLAC_OK;
 }
 
@@ -358,7 +358,7 @@ int64_t swc_flac_decode(const uint8_t* data, size_t n, int32_t* out, int64_t cap
         else if (ca == 10) {                                                                 /* mid, side */
             for (int i = 0; i < bs; ++i) {
                 int64_t m = a[i], sd = s2[i];
-                m = (m << 1) | (sd & 1);
+                m = m * 2 + (sd & 1);
                 a[i] = (m + sd) >> 1;
                 s2[i] = (m - sd) >> 1;
             }

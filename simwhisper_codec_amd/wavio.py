@@ -99,6 +99,12 @@ def _io():
 
 def _read_flac(path):
     """-> (float32 array (n, channels) in [-1, 1), sample rate).  Raises ValueError on anything that does not verify."""
+    pcm, sr, bits = _decode_flac(path)
+    return pcm.astype(np.float32) / np.float32(2.0 ** (bits - 1)), sr
+
+
+def _decode_flac(path):
+    """-> (int32 array (n, channels), sample rate, bits per sample)"""
     import ctypes as C
     with open(path, "rb") as f:
         data = f.read()
@@ -120,7 +126,7 @@ def _read_flac(path):
         raise ValueError(f"{path}: {_FLAC_ERRORS.get(int(n), int(n))}")
     if not md5.value:
         logging.warning(f"{path}: the stream carries no MD5 signature; frame CRCs verified only")
-    return out[:n].astype(np.float32) / np.float32(1 << (bits.value - 1)), int(sr.value)
+    return out[:n], int(sr.value), int(bits.value)
 
 
 def load_audio(audio_path, target_sample_rate):

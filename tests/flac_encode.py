@@ -71,8 +71,8 @@ def put_residual(bw, res, bs, order, porder, rice2=False, escape_part=None):
         cnt = (bs >> porder) - (order if p == 0 else 0)
         seg = res[idx:idx + cnt]
         idx += cnt
-        if escape_part == p:
-            raw = max([int(abs(int(x))).bit_length() + 1 for x in seg] + [1])
+        raw = max([int(abs(int(x))).bit_length() + 1 for x in seg] + [1])
+        if escape_part == p and raw <= 31:
             bw.put(esc, pbits)
             bw.put(raw, 5)
             for x in seg:

@@ -28,13 +28,14 @@ def _signal(n, ch, bps, seed):
 def _roundtrip(tmp_path, x, sr, bps, **kw):
     p = tmp_path / "t.flac"
     p.write_bytes(fe.encode(x, sr, bps, **kw))
-    got, got_sr = wavio._read_flac(str(p))
-    assert got_sr == sr and got.shape == x.shape
-    assert np.array_equal(np.round(got.astype(np.float64) * (1 << (bps - 1))).astype(np.int64), x)
+    pcm, got_sr, got_bits = wavio._decode_flac(str(p))
+    assert got_sr == sr and got_bits == bps and np.array_equal(pcm.astype(np.int64), x)
+    got, _ = wavio._read_flac(str(p))
+    assert got.dtype == np.float32 and got.shape == x.shape and float(np.abs(got).max()) <= 1.0
     return p
 
 
-@pytest.mark.parametrize("ch,bps", [(1, 16), (2, 16), (1, 24), (2, 24), (1, 8), (2, 12)])
+@pytest.mark.parametrize("ch,bps", [(1, 16), (2, 16), (1, 24), (2, 24), (1, 8), (2, 12), (2, 32), (1, 20)])
 def test_flac_subframe_types_and_stereo_modes(tmp_path, ch, bps):
     n = 5 * 1024 + 333
     x = _signal(n, ch, bps, seed=ch * 100 + bps)
@@ -92,3 +93,36 @@ def test_flac_corruption_is_detected(tmp_path):
     p.write_bytes(b"fLaC")
     with pytest.raises(ValueError):
         wavio._read_flac(str(p))
+
+
+def test_flac_decoder_survives_damaged_streams(tmp_path):
+    """random byte damage, truncation and garbage tails: the decoder must answer with an error or (when the damage is
+    outside what the CRCs and the MD5 cover, e.g. in STREAMINFO's frame-size hints) the right samples, never crash."""
+    x = _signal(3000, 2, 16, seed=21)
+    good = fe.encode(x, 16000, 16, blocksize=1024,
+                     plan=lambda fi, c: [0, 8, 9, 10][fi % 4] if c is None else dict(kind=("lpc", 6), porder=1, rice2=bool(fi % 2)))
+    g = np.random.default_rng(0)
+    p = tmp_path / "f.flac"
+    ok = bad = 0
+    for trial in range(400):
+        b = bytearray(good)
+        mode = trial % 4
+        if mode == 0:
+            for _ in range(1 + trial % 3):
+                b[int(g.integers(0, len(b)))] ^= int(g.integers(1, 256))
+        elif mode == 1:
+            b = b[: int(g.integers(0, len(b)))]
+        elif mode == 2:
+            i = int(g.integers(4, len(b)))
+            b[i:i + 8] = bytes(g.integers(0, 256, 8, dtype=np.uint8))
+        else:
+            b += bytes(g.integers(0, 256, int(g.integers(1, 64)), dtype=np.uint8))
+        p.write_bytes(bytes(b))
+        try:
+            got, sr = wavio._read_flac(str(p))
+            ok += 1
+            assert np.array_equal(np.round(got.astype(np.float64) * 32768).astype(np.int64), x)
+        except ValueError:
+            bad += 1
+    assert bad > 250 and ok + bad == 400
+
