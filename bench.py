@@ -180,6 +180,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # SWC_BENCH_BACKEND=gloo: rehearsal of the multi-rank control flow on ONE card (every rank computes on a visible GPU,
+    # LOCAL_RANK modulo their number; traffic goes through host memory).  RCCL refuses two ranks on one GPU, so this is the
+    # only way to run `--gpus 2` on a one-GPU box; the numbers it prints are not the metric.
+    backend = os.environ.get("SWC_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # one process per GPU over RCCL.  A single rank also gets its (one-member) group, so that N = 1 runs the very code
@@ -194,8 +199,11 @@ def main():
             import datetime
             # a failed peer must not leave the others waiting for the default 10 minutes
             with _StdoutToStderr():
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
-                                        timeout=datetime.timedelta(seconds=240))
+                if backend == "nccl":
+                    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                            timeout=datetime.timedelta(seconds=240))
+                else:
+                    dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=240))
                 dist.barrier()  # creates the communicator now (and prints RCCL's banner to stderr)
                 torch.cuda.synchronize(dev)
             use_dist = True
@@ -243,7 +251,7 @@ def main():
         elapsed = time.perf_counter() - t0
         check(out)
         if use_dist:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
@@ -266,7 +274,7 @@ def main():
     res_b, b_err = None, None
     if use_dist:
         try:
-            dp = DataParallelCodec(model, dev)
+            dp = DataParallelCodec(model, dev, comm_device=None if backend == "nccl" else "cpu")
             owned = [w.to(dev) for w in all_wavs] if rank == 0 else None
 
             def step_dp():
@@ -291,7 +299,8 @@ def main():
     el_main = el_b if res_b is not None else el_a
 
     if rank == 0:
-        par = (f"dp{world}: rank 0 scatters the audio / gathers codes + waveforms over RCCL point-to-point (xGMI), "
+        via = "RCCL point-to-point (xGMI)" if backend == "nccl" else f"{backend} through host memory (REHEARSAL on shared cards, not the metric)"
+        par = (f"dp{world}: rank 0 scatters the audio / gathers codes + waveforms over {via}, "
                f"utterance shards of {args.batch} per GPU" if res_b is not None
                else f"dp{world} (independent utterance shards, no collective)")
         line = {

@@ -145,3 +145,27 @@ def test_cli_two_ranks_writes_the_single_gpu_files(tmp_path):
     assert names == sorted(os.listdir(out2)) and len(names) == 5
     for n in names:
         assert (out1 / n).read_bytes() == (out2 / n).read_bytes(), n
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), rehearsed on one card:
+    SWC_BENCH_BACKEND=gloo carries the traffic through host memory because RCCL refuses two ranks on one GPU.  Checks the
+    multi-rank control flow of the bench: one JSON line, from rank 0, covering all ranks' utterances."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SWC_BENCH_BACKEND="gloo")
+    env.pop("SWC_LIB", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--batch", "4", "--seconds", "3", "--cpu-baseline", "off"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert "8 utterances in all" in d["config"]["workload"] and d["independent_shards"]["value"] > 0
+    assert d["roofline"]["frac"] > 0
+
