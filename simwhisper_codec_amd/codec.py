@@ -363,6 +363,23 @@ class AudioCodec(nn.Module):
         self._pk_key = key
         return self._pk
 
+    _TUNABLES = ("saturation_policy", "varlen_packing", "length_bucketing", "bucket_overhead_tokens", "trim_vocos", "ragged_vocos",
+                 "vocos_streams", "vocos_phase_us", "vocos_split_override", "max_rows_per_call", "fused_mlp_min_rows")
+
+    def replica(self):
+        """A second AudioCodec over the SAME device-resident operands (nothing is copied or re-packed), with its own
+        staging ring, range counters, side stream and caches: what a second host thread needs to run batches on its own
+        stream beside this one (pipeline.InFlight).  A replica cannot re-pack: if its split-f16 operands clip it raises
+        instead of falling back to exact-f32 operands (use precision="mixed_f32" on the original then)."""
+        P = self._packed()
+        r = AudioCodec(self.generator_params, precision=self._precision, _packed_file="<replica of a loaded model>")
+        r = r.to(self._buffers_device()).eval()
+        r._pk, r._pk_key = P, self._pk_key
+        for name in self._TUNABLES:
+            if name in self.__dict__:
+                setattr(r, name, self.__dict__[name])
+        return r
+
     def export_packed(self, path):
         """Write this model's GEMM-ready operands (current precision preset, current device) to a packed-operand
         .safetensors file that load_from_checkpoint() maps straight to the device (tools/pack_checkpoint.py --fold)."""
