@@ -272,32 +272,6 @@ def main():
     res_a = {"value": round(world * args.batch * args.seconds * args.steps / el_a, 2),
              "ms_per_step": round(1e3 * el_a / args.steps, 3), "ms_per_step_median": round(statistics.median(steps_a), 3)}
 
-    # ---- measurement A2: the same K steps with TWO batches in flight (pipeline.InFlight: two host threads, two streams, two
-    # model objects over one set of operands): what the serving loop around the path gains when consecutive batches
-    # overlap.  Reported beside `value`, never as `value`: a step there is one batch at a time.
-    res_a2 = None
-    try:
-        from simwhisper_codec_amd.pipeline import InFlight
-        with InFlight(model, 2) as pipe:
-            def step_pipe(mdl, w):
-                return mdl.decode(mdl.encode(w, overlap_seconds=10, device=dev)["codes_list"], overlap_seconds=10, device=dev)
-            pipe.map(step_pipe, [mine] * max(2, args.warmup))
-            fence()
-            t0 = time.perf_counter()
-            outs = pipe.map(step_pipe, [mine] * args.steps)
-            fence()
-            el_a2 = time.perf_counter() - t0
-            check_local(outs[-1])
-            if use_dist:
-                t = torch.tensor([el_a2], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el_a2 = float(t.item())
-            res_a2 = {"value": round(world * args.batch * args.seconds * args.steps / el_a2, 2),
-                      "ms_per_step": round(1e3 * el_a2 / args.steps, 3),
-                      "note": "independent shards, two batches in flight per GPU (two streams); results bit-identical to one at a time"}
-    except Exception as e:  # an extra: never fails the bench line
-        res_a2 = {"error": f"{type(e).__name__}: {e}"}
-
     # ---- measurement B: rank 0 scatters / gathers over RCCL (configs[3])
     res_b, b_err = None, None
     if use_dist:
@@ -323,6 +297,32 @@ def main():
                 b_err = f"{type(e).__name__}: {e}"
             else:
                 raise
+    # ---- measurement C (after the two metric measurements, so that it cannot warm the chip for them): the same K steps with TWO batches in flight (pipeline.InFlight: two host threads, two streams, two
+    # model objects over one set of operands): what the serving loop around the path gains when consecutive batches
+    # overlap.  Reported beside `value`, never as `value`: a step there is one batch at a time.
+    res_a2 = None
+    try:
+        from simwhisper_codec_amd.pipeline import InFlight
+        with InFlight(model, 2) as pipe:
+            def step_pipe(mdl, w):
+                return mdl.decode(mdl.encode(w, overlap_seconds=10, device=dev)["codes_list"], overlap_seconds=10, device=dev)
+            pipe.map(step_pipe, [mine] * max(2, args.warmup))
+            fence()
+            t0 = time.perf_counter()
+            outs = pipe.map(step_pipe, [mine] * args.steps)
+            fence()
+            el_a2 = time.perf_counter() - t0
+            check_local(outs[-1])
+            if use_dist:
+                t = torch.tensor([el_a2], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el_a2 = float(t.item())
+            res_a2 = {"value": round(world * args.batch * args.seconds * args.steps / el_a2, 2),
+                      "ms_per_step": round(1e3 * el_a2 / args.steps, 3),
+                      "note": "independent shards, two batches in flight per GPU (two streams); results bit-identical to one at a time"}
+    except Exception as e:  # an extra: never fails the bench line
+        res_a2 = {"error": f"{type(e).__name__}: {e}"}
+
     main_res = res_b if res_b is not None else res_a
     el_main = el_b if res_b is not None else el_a
 
