@@ -297,16 +297,17 @@ class AudioCodec(nn.Module):
         def __exit__(self, et, ev, tb):
             self.m.__dict__["_defer"] -= 1
             if et is None and self.m.__dict__["_defer"] == 0 and self.m.__dict__.pop("_defer_pending", False):
-                self.clipped = self.m._check_clipping()
+                self.clipped = self.m._check_clipping(self.m.__dict__.pop("_defer_ran_as", None))
             return False
 
     def deferred_range_check(self):
         return AudioCodec._Deferred(self)
 
-    def _check_clipping(self):
+    def _check_clipping(self, ran_as=None):
         """Read the counters (synchronises), apply the policy.  True: split-f16 operands clipped since the last check and the
-        model switched to exact-f32 encoder operands (policy "fallback"): the caller re-runs."""
-        e = PRECISIONS[self._precision][0]
+        model switched to exact-f32 encoder operands (policy "fallback"): the caller re-runs.  ran_as: the preset the checked
+        kernels ran with (with batches in flight another thread may have switched this model's preset meanwhile)."""
+        e = PRECISIONS[ran_as or self._precision][0]
         st = self._sat_state(self._buffers_device())
         n = self.saturation_count()
         new16, new8 = n["f16s"] - st["seen"][0], n["fp8"] - st["seen"][1]
@@ -322,23 +323,55 @@ class AudioCodec(nn.Module):
             if self.saturation_policy == "fallback":
                 logging.warning("split-f16 operands clipped (%d producer threads saw |activation| >= 1023): re-running this "
                                 "call on exact-f32 encoder operands; the model stays on precision='mixed_f32'", new16)
-                self.precision = "mixed_f32" if self._precision == "mixed" else "fp32"
+                self._switch_precision("mixed_f32" if (ran_as or self._precision) in ("mixed", "mixed_f32") else "fp32")
                 return True
         return False
+
+    _REPACK_LOCK = threading.RLock()
+
+    def _switch_precision(self, p):
+        """the range-guard fallback.  A replica has no weights of its own to pack from: its origin packs the new preset
+        (once, under a lock: replicas run on other threads) and the replica adopts those operands."""
+        origin = self.__dict__.get("_origin")
+        if origin is None:
+            with AudioCodec._REPACK_LOCK:
+                if self._precision != p:
+                    self.precision = p
+                self._packed()
+            return
+        with AudioCodec._REPACK_LOCK:
+            if origin._precision != p:
+                origin.precision = p
+            P = origin._packed()
+        self._precision, self._pk, self._pk_key = p, P, origin._pk_key
+
+    def _follow_origin(self):
+        """a replica whose origin has switched presets meanwhile (another thread's batch clipped) follows it"""
+        origin = self.__dict__.get("_origin")
+        if origin is not None and origin._precision != self._precision:
+            with AudioCodec._REPACK_LOCK:
+                P = origin._packed()
+                self._precision, self._pk, self._pk_key = origin._precision, P, origin._pk_key
 
     def _guarded_encode(self, run):
         """run(P) enqueues the encode-side kernels of one call and returns its outputs.  After it, the clip counters are
         read back (one 8-byte copy + stream sync per call; presets without reduced-range encode operands skip it)."""
-        P = self._packed()  # raises for a model that is not on the HIP device
-        e = PRECISIONS[self._precision][0]
-        if (e != "f16s" and self._precision != "fp8") or self.saturation_policy == "off":
+        self._follow_origin()
+        with AudioCodec._REPACK_LOCK:  # (preset, operands) as one consistent pair: another thread may be switching presets
+            ran_as = self._precision
+            P = self._packed()  # raises for a model that is not on the HIP device
+        e = PRECISIONS[ran_as][0]
+        if (e != "f16s" and ran_as != "fp8") or self.saturation_policy == "off":
             return run(P)
         out = run(P)
         if self.__dict__.get("_defer", 0) > 0:  # inside deferred_range_check(): one read-back when the block ends
             self.__dict__["_defer_pending"] = True
+            self.__dict__["_defer_ran_as"] = ran_as
             return out
-        if self._check_clipping():
-            out = run(self._packed())
+        if self._check_clipping(ran_as):
+            with AudioCodec._REPACK_LOCK:
+                P = self._packed()
+            out = run(P)
         return out
 
     # ------------------------------------------------------------- packing
@@ -369,12 +402,13 @@ class AudioCodec(nn.Module):
     def replica(self):
         """A second AudioCodec over the SAME device-resident operands (nothing is copied or re-packed), with its own
         staging ring, range counters, side stream and caches: what a second host thread needs to run batches on its own
-        stream beside this one (pipeline.InFlight).  A replica cannot re-pack: if its split-f16 operands clip it raises
-        instead of falling back to exact-f32 operands (use precision="mixed_f32" on the original then)."""
+        stream beside this one (pipeline.InFlight).  A replica cannot pack by itself: when its split-f16 operands clip, the
+        origin packs the exact-f32 preset (range-guard fallback) and every replica follows."""
         P = self._packed()
         r = AudioCodec(self.generator_params, precision=self._precision, _packed_file="<replica of a loaded model>")
         r = r.to(self._buffers_device()).eval()
         r._pk, r._pk_key = P, self._pk_key
+        r.__dict__["_origin"] = self.__dict__.get("_origin") or self
         for name in self._TUNABLES:
             if name in self.__dict__:
                 setattr(r, name, self.__dict__[name])

@@ -105,6 +105,29 @@ def test_outlier_checkpoint_falls_back_and_stays_bit_exact(caplog):
     assert m2.saturation_count() == {"f16s": 0, "fp8": 0} and m2.precision == "mixed"
 
 
+def test_replica_follows_the_range_fallback():
+    """Batches in flight (pipeline.InFlight): a replica has no weights to pack from.  When ITS batch clips, the origin packs
+    the exact-f32 preset once and the replica adopts it; the other replica follows at its next call.  Codes = the oracle's."""
+    from oracle.ref_cpu import Oracle
+    from simwhisper_codec_amd import synth
+    from simwhisper_codec_amd.pipeline import InFlight
+    tag = "tiny"
+    sd = _outlier_state_dict(tag)
+    wavs = [synth.synth_audio(30000, index=300, kind="speech"), synth.synth_audio(21111, index=301, kind="noise")]
+    want = Oracle(PARAMS[tag](), sd).encode(wavs, trim=True)["codes_list"]
+    m = _model(tag, "mixed", sd)
+    assert m.precision == "mixed"
+    dw = [w.to(DEV) for w in wavs]
+    with InFlight(m, 2) as pipe:
+        outs = pipe.map(lambda mdl, w: mdl.encode(w)["codes_list"], [dw] * 6)
+        outs += [mm.encode(dw)["codes_list"] for mm in pipe.models]   # a model that sat idle follows at its next call
+        assert all(mm.precision == "mixed_f32" for mm in pipe.models)
+        assert pipe.models[1]._packed() is m._packed()
+    for got in outs:
+        for a, b in zip(got, want):
+            assert torch.equal(a.cpu().long(), b.long())
+
+
 def test_device_guard(monkeypatch):
     """Kernels run on the CURRENT device's stream: a tensor of another GPU is refused, and the public entry points make
     the model's GPU current (no second GPU needed: the current-device query is patched)."""
