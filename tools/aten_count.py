@@ -1,11 +1,14 @@
+#!/usr/bin/env python3
+"""ATen / copy kernels that one steady-state encode+decode step still launches beside the swc_* kernels (torch profiler)."""
 import sys, os
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import torch, yaml
 from torch.profiler import profile, ProfilerActivity
 from simwhisper_codec_amd import synth
 from simwhisper_codec_amd.codec import AudioCodec
 from bench import bench_inputs
-gp = yaml.safe_load(open("/root/repo/config/SimWhisperCodec.yaml"))["generator_params"]
+gp = yaml.safe_load(open(os.path.join(ROOT, "config", "SimWhisperCodec.yaml")))["generator_params"]
 m = AudioCodec(gp, precision="mixed"); m.load_state_dict(synth.synth_state_dict(gp)); m = m.to("cuda:0").eval()
 wavs = [w.cuda() for w in bench_inputs(32, 160000)]
 for _ in range(3): m.decode(m.encode(wavs)["codes_list"])

@@ -1,9 +1,12 @@
+#!/usr/bin/env python3
+"""What the range guard costs per step: saturation_policy "fallback" (one counter read-back per encode) vs "off"."""
 import sys, time, torch, yaml, os
-sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from simwhisper_codec_amd import synth
 from simwhisper_codec_amd.codec import AudioCodec
 from bench import bench_inputs
-gp = yaml.safe_load(open("/root/repo/config/SimWhisperCodec.yaml"))["generator_params"]
+gp = yaml.safe_load(open(os.path.join(ROOT, "config", "SimWhisperCodec.yaml")))["generator_params"]
 sd = synth.synth_state_dict(gp)
 for prec in ("mixed", "fp8"):
     m = AudioCodec(gp, precision=prec); m.load_state_dict(sd); m = m.to("cuda:0").eval()
