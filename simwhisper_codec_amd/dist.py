@@ -197,22 +197,31 @@ class DataParallelCodec:
                                  pad_to_length=t_max)["syn_wav_list"] if codes else []
         return self._pad_batch(list(wavs), [int(w.numel()) for w in wavs], torch.float32, Lw)
 
+    # per-utterance views of the gathered buffers.  One unbind per shard instead of one Python slice per utterance (a view
+    # costs microseconds of host time; at 8 x 32 utterances the per-row slices of both lists were ~2 ms of every step on
+    # rank 0, with the GPUs idle); only rows shorter than the buffer are narrowed.
     def _split_codes(self, got, parts, clen):
         G = self.codec.num_groups
         out = []
         for (a, b), buf in zip(parts, got):
+            if b == a:
+                continue
             buf = buf if buf.device == self.device else buf.to(self.device)
-            for i in range(a, b):
-                out.append(buf[(i - a) * G:(i - a + 1) * G, : clen[i]])
+            Lc = buf.shape[1]
+            rows = buf.view(b - a, G, Lc).unbind(0)
+            out.extend(r if clen[a + k] == Lc else r[:, : clen[a + k]] for k, r in enumerate(rows))
         return out
 
     def _split_wavs(self, got, parts, clen):
         up = self.codec.decoder_upsample_rate
         out = []
         for (a, b), buf in zip(parts, got):
+            if b == a:
+                continue
             buf = buf if buf.device == self.device else buf.to(self.device)
-            for i in range(a, b):
-                out.append(buf[i - a, : up * clen[i]])
+            Lw = buf.shape[1]
+            rows = buf.unbind(0)
+            out.extend(r if up * clen[a + k] == Lw else r[: up * clen[a + k]] for k, r in enumerate(rows))
         return out
 
     # ------------------------------------------------------------------ public surface
