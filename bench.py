@@ -23,7 +23,15 @@ Rank 0 prints ONE JSON line, with
                  its dtype; traffic = HBM bytes per launch from the committed rocprofv3 --pmc passes, tagged with the commit
                  they were taken at (a stale value is visible as a different commit).
   cpu_baseline — the CPU oracle (oracle/ref_cpu.py, the reference's algorithm incl. its 30 s padding) timed on this
-                 box's host cores on a bounded sample of the same workload (N = 1 only): 1 warm-up + 3 timed passes, median.
+                 box's host cores on a bounded sample of the same workload (N = 1 only): B = 8 x 10 s (BASELINE.json
+                 configs[1]'s shape, the first 8 draws of the same generator), 1 warm-up + 3 timed passes, median (~60 s).
+  parity       — the run checks its own answer: the codes of utterance 0 of the LAST timed step must equal the CPU oracle's
+                 bit for bit and its waveform must lie within the bf16-decode tolerance of the oracle's (N = 1, cpu baseline
+                 on: the oracle's warm-up pass supplies them); otherwise utterance 0 encoded alone on the GPU (rows of a
+                 batch are independent).  A wrong answer fails the bench.
+  other_configs — after the metric measurements (N = 1): the other BASELINE.json configs, a few steps each, every one with
+                 its own dominant-kernel roofline: B = 8 x 10 s `bf16` (configs[1]), 32 x 30 s `mixed` (configs[2]),
+                 32 x 10 s `fp8` (configs[4]) and 32 x 10 s `fp32` (the reference's own arithmetic).  Never `value`.
 """
 import argparse
 import json
@@ -89,6 +97,38 @@ def pmc_traffic(kind):
         return None, None
 
 
+KERNEL_NAMES = {"convnext_bf16": "swc_convnext_block (bf16)"}
+
+
+def roofline_of(summ, step_ms, n_sampled, brief=False):
+    """the `roofline` object from a KernelTimer summary: the dominant family (by accumulated device time) priced against the
+    dense MFMA peak of its dtype, the others listed with their own fraction."""
+    if not summ or not n_sampled:
+        return None
+    kind = max(summ, key=lambda k: summ[k]["ms"])
+    d = summ[kind]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    out = {"bound": "mfma", "kernel": KERNEL_NAMES.get(kind, f"swc_gemm ({kind})"), "achieved": round(ach, 2),
+           "peak": round(PEAK_TFLOPS[kind], 1), "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[kind], 4),
+           "launches_per_step": d["launches"] // n_sampled, "share_of_step": round(d["ms"] / n_sampled / step_ms, 3),
+           "other": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                         "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS[k], 4),
+                         "launches_per_step": v["launches"] // n_sampled,
+                         "share_of_step": round(v["ms"] / n_sampled / step_ms, 3)}
+                     for k, v in summ.items() if k != kind}}
+    if brief:
+        return out
+    traffic, src = pmc_traffic(kind)
+    tot_ms = sum(v["ms"] for v in summ.values())
+    tot_fl = sum(v["flops"] for v in summ.values())
+    out.update({"traffic": traffic, "traffic_source": src, "sampled_steps": n_sampled,
+                "avg_launch_ms": round(d["ms"] / d["launches"], 4),
+                "all_mfma_kernels": {"TFLOP/s": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                     "share_of_step": round(tot_ms / n_sampled / step_ms, 3)},
+                "commit": git_commit()})
+    return out
+
+
 def bench_inputs(n_utt, n_samples):
     """SURVEY.md 8d / BASELINE.md 2: 0.1 * N(0,1), torch.Generator().manual_seed(1234), one draw per utterance in order."""
     g = torch.Generator().manual_seed(1234)
@@ -113,15 +153,19 @@ def cpu_baseline(gp, sd, shapes, seconds, threads):
     ora = Oracle(gp, sd)
     res = []
     t_all = time.perf_counter()
+    first = None
     for n_utt in shapes:
         wavs = bench_inputs(n_utt, int(seconds * 16000))
         times = []
         for it in range(4):
             t0 = time.perf_counter()
             codes = ora.encode(wavs)["codes_list"]
-            ora.decode(codes)
+            wav = ora.decode(codes)["syn_wav_list"]
             if it:
                 times.append(time.perf_counter() - t0)
+            elif first is None:  # the oracle's answer for the first utterances of the workload: the bench's parity check
+                n_code = int(seconds * 16000) // 1280
+                first = {"codes": [c[:, :n_code].long() for c in codes], "wav": [w[: n_code * 1280].float() for w in wav]}
         res.append({"batch": n_utt, "audio-s/s": round(n_utt * seconds / statistics.median(times), 3),
                     "pass_s": [round(t, 2) for t in times]})
     head = res[-1]
@@ -129,7 +173,7 @@ def cpu_baseline(gp, sd, shapes, seconds, threads):
             "sample": f"{head['batch']} x {seconds:g} s utterances (same generator as the GPU run), 1 warm-up + 3 timed "
                       f"encode+decode passes, median; fp32, oracle/ref_cpu.py (reference algorithm incl. 30 s padding); "
                       f"{time.perf_counter() - t_all:.0f} s of CPU work",
-            "shapes": res}
+            "shapes": res}, first
 
 
 class _StdoutToStderr:
@@ -171,10 +215,15 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--precision", default="mixed", choices=["fp32", "mixed", "mixed_f32", "bf16", "fp8"])
-    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "full", "off"],
-                    help="sample: 2 utterances (~15 s of CPU work); full: B=8 and B=32 as BASELINE.md 2 (minutes)")
+    ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "small", "full", "off"],
+                    help="sample: B=8 x 10 s, BASELINE.json configs[1]'s shape (~60 s of CPU work); small: 2 utterances "
+                         "(~15 s); full: B=8 and B=32 as BASELINE.md 2 (minutes)")
     ap.add_argument("--no-timer", action="store_true", help="no per-launch event pairs (no roofline object)")
     ap.add_argument("--no-dist", action="store_true", help="N=1 only: skip the process group and the scatter/gather measurement")
+    ap.add_argument("--no-inflight", action="store_true",
+                    help="skip the two-batches-in-flight extra (profiling passes: only serial steps in the kernel trace)")
+    ap.add_argument("--other-configs", default="auto", choices=["auto", "on", "off"],
+                    help="the other BASELINE.json configs after the metric (auto: N=1 and the default workload / preset)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -220,13 +269,63 @@ def main():
 
     gp = yaml.safe_load(open(os.path.join(ROOT, "config", "SimWhisperCodec.yaml")))["generator_params"]
     sd = synth.synth_state_dict(gp)
-    model = AudioCodec(gp, precision=args.precision)
-    model.load_state_dict(sd, strict=True)
-    model = model.to(dev).eval()
+
+    def build(precision):
+        m = AudioCodec(gp, precision=precision)
+        m.load_state_dict(sd, strict=True)
+        return m.to(dev).eval()
+
+    model = build(args.precision)
     n = int(args.seconds * 16000)
     all_wavs = bench_inputs(world * args.batch, n)  # the same draws on every rank; a rank keeps what it needs
     mine = [w.to(dev) for w in all_wavs[rank * args.batch:(rank + 1) * args.batch]]
     n_out = (n // 1280) * 1280
+
+    # ---- the answer the timed steps must reproduce (outside every timed region).  N = 1 with the CPU baseline on: the
+    # oracle's own codes / waveform of the first utterances (its warm-up pass; the baseline is timed here, before the GPU
+    # measurements, for that reason).  Otherwise: utterance 0 of this rank encoded + decoded ALONE on the GPU — rows of a
+    # uniform batch are independent, so the batched step must give the same bits.
+    cpu_res, expect = None, None
+    exact_codes = args.precision in ("fp32", "mixed", "mixed_f32")  # bf16 / fp8 encoders agree statistically only
+    wav_tol = 5e-5 if args.precision == "fp32" else 5e-2         # tests/test_parity_gpu.py TOL_FP32 / TOL_BF16
+    if world == 1 and rank == 0 and args.cpu_baseline != "off":
+        threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        shapes = {"sample": [min(8, args.batch)], "small": [min(2, args.batch)], "full": [8, 32]}[args.cpu_baseline]
+        cpu_res, first = cpu_baseline(gp, sd, shapes, args.seconds, threads)
+        expect = {"source": "oracle/ref_cpu.py (CPU, fp32)", "codes": first["codes"], "wav": first["wav"]}
+    else:
+        r0 = model.encode(mine[:1], overlap_seconds=10, device=dev)["codes_list"]
+        w0 = model.decode(r0, overlap_seconds=10, device=dev)["syn_wav_list"]
+        expect = {"source": "utterance 0 alone on the GPU (batch independence)", "codes": [r0[0].long().cpu()],
+                  "wav": [w0[0].float().cpu()]}
+        exact_codes = True  # (the waveform tolerance stays: a batch of one takes the two-GEMM form of the ConvNeXt blocks)
+    parity = {}
+
+    def check_answer(codes_list, wav_list):
+        """codes of utterance 0 bit for bit (presets with an f32-class encoder), waveform of utterance 0 within the decode
+        tolerance; agreement over all the rows the source covers is reported."""
+        mism = total = 0
+        worst = 0.0
+        for i, want in enumerate(expect["codes"]):
+            got = codes_list[i].long().cpu()
+            assert got.shape == want.shape, (got.shape, want.shape)
+            d = int((got != want).sum())
+            if i == 0 and exact_codes:
+                assert d == 0, f"bench: {d} of {want.numel()} codes of utterance 0 differ from {expect['source']}"
+            mism += d; total += want.numel()
+        if exact_codes:  # waveform given the SAME codes; presets with a statistical encoder differ in codes
+            for i, want in enumerate(expect["wav"]):
+                got = wav_list[i].float().cpu()
+                assert got.shape == want.shape, (got.shape, want.shape)
+                if int((codes_list[i].long().cpu() != expect["codes"][i]).sum()):
+                    continue  # a flipped borderline code changes the waveform legitimately
+                e = float((got - want).abs().max() / (want.abs().max() + 1e-12))
+                if i == 0:
+                    assert e <= wav_tol, f"bench: waveform of utterance 0 is {e:.3e} (relative to peak) from {expect['source']}, tolerance {wav_tol}"
+                worst = max(worst, e)
+        parity.update({"against": expect["source"], "utterances": len(expect["codes"]), "codes_compared": total,
+                       "code_mismatches": mism, "codes_must_match": bool(exact_codes), "waveform_rel_err_max": worst,
+                       "waveform_tolerance": wav_tol})
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -251,21 +350,37 @@ def main():
         ops.PROFILER = None
         fence()
         elapsed = time.perf_counter() - t0
-        check(out)
+        # the check is collective: a rank whose answer is wrong must not leave the others inside the next all-reduce
+        # (they would pair up with a later collective of this rank): every rank learns the verdict, all raise together
+        err = None
+        try:
+            check(out)
+        except AssertionError as e:
+            err = e
         if use_dist:
-            t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            t = torch.tensor([elapsed, 0.0 if err is None else 1.0], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed, bad = float(t[0].item()), float(t[1].item()) > 0
+        else:
+            bad = err is not None
+        if err is not None:
+            raise err
+        if bad:
+            raise AssertionError("bench: the answer check failed on another rank")
         per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
         return elapsed, per_step, len(sampled)
 
     # ---- measurement A: independent shards (no data-path traffic)
     def step_local():
         enc = model.encode(mine, overlap_seconds=10, device=dev)
-        return model.decode(enc["codes_list"], overlap_seconds=10, device=dev)
+        out = model.decode(enc["codes_list"], overlap_seconds=10, device=dev)
+        out["codes_list"] = enc["codes_list"]
+        return out
 
     def check_local(out):
         assert len(out["syn_wav_list"]) == args.batch and out["syn_wav_list"][0].shape[0] == n_out
+        if rank == 0:
+            check_answer(out["codes_list"], out["syn_wav_list"])
 
     timer = None if args.no_timer else KernelTimer()
     el_a, steps_a, n_sampled = timed(step_local, check_local, None if use_dist else timer)
@@ -286,6 +401,7 @@ def main():
                 if rank == 0:
                     assert len(out["syn_wav_list"]) == world * args.batch and out["syn_wav_list"][-1].shape[0] == n_out
                     assert len(out["codes_list"]) == world * args.batch and out["codes_list"][-1].shape[-1] == n // 1280
+                    check_answer(out["codes_list"], out["syn_wav_list"])
 
             el_b, steps_b, n_sampled = timed(step_dp, check_dp, timer)
             res_b = {"value": round(world * args.batch * args.seconds * args.steps / el_b, 2),
@@ -302,17 +418,26 @@ def main():
     # overlap.  Reported beside `value`, never as `value`: a step there is one batch at a time.
     res_a2 = None
     try:
+        if args.no_inflight:
+            raise InterruptedError
         from simwhisper_codec_amd.pipeline import InFlight
         with InFlight(model, 2) as pipe:
             def step_pipe(mdl, w):
-                return mdl.decode(mdl.encode(w, overlap_seconds=10, device=dev)["codes_list"], overlap_seconds=10, device=dev)
+                enc = mdl.encode(w, overlap_seconds=10, device=dev)
+                out = mdl.decode(enc["codes_list"], overlap_seconds=10, device=dev)
+                out["codes_list"] = enc["codes_list"]
+                return out
             pipe.map(step_pipe, [mine] * max(2, args.warmup))
             fence()
             t0 = time.perf_counter()
             outs = pipe.map(step_pipe, [mine] * args.steps)
             fence()
             el_a2 = time.perf_counter() - t0
-            check_local(outs[-1])
+            wrong = None
+            try:
+                check_local(outs[-1])
+            except AssertionError as e:  # reported in the field; the all-reduce below still happens on every rank
+                wrong = str(e)
             if use_dist:
                 t = torch.tensor([el_a2], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -320,11 +445,54 @@ def main():
             res_a2 = {"value": round(world * args.batch * args.seconds * args.steps / el_a2, 2),
                       "ms_per_step": round(1e3 * el_a2 / args.steps, 3),
                       "note": "independent shards, two batches in flight per GPU (two streams); results bit-identical to one at a time"}
+            if wrong:
+                res_a2 = {"error": f"answer check failed: {wrong}"}
+    except InterruptedError:
+        res_a2 = {"skipped": "--no-inflight"}
     except Exception as e:  # an extra: never fails the bench line
         res_a2 = {"error": f"{type(e).__name__}: {e}"}
 
     main_res = res_b if res_b is not None else res_a
     el_main = el_b if res_b is not None else el_a
+
+    # ---- the other BASELINE.json configs (N = 1, after everything the metric needs): a few steps each of encode()+decode()
+    # on this same GPU, never `value`.  Each line carries its own dominant-kernel roofline (sampled on its last step).
+    others = None
+    default_run = args.batch == 32 and args.seconds == 10.0 and args.precision == "mixed"
+    if world == 1 and (args.other_configs == "on" or (args.other_configs == "auto" and default_run)):
+        others = {}
+        del model
+        torch.cuda.empty_cache()
+        for tag, (ob, osec, oprec, osteps) in {
+                "configs[1] batch=8x10s bf16": (8, 10.0, "bf16", 10),
+                "configs[2] batch=32x30s mixed": (32, 30.0, "mixed", 4),
+                "configs[4] batch=32x10s fp8 encoder linears": (32, 10.0, "fp8", 8),
+                "batch=32x10s fp32 (the reference's arithmetic)": (32, 10.0, "fp32", 3)}.items():
+            try:
+                mdl = build(oprec)
+                w = [x.to(dev) for x in bench_inputs(ob, int(osec * 16000))]
+
+                def ostep():
+                    return mdl.decode(mdl.encode(w, overlap_seconds=10, device=dev)["codes_list"], overlap_seconds=10, device=dev)
+                for _ in range(2):
+                    ostep()
+                otimer = KernelTimer()
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for i in range(osteps):
+                    ops.PROFILER = otimer if i == osteps - 1 else None
+                    o = ostep()
+                ops.PROFILER = None
+                torch.cuda.synchronize(dev)
+                el = time.perf_counter() - t0
+                assert len(o["syn_wav_list"]) == ob and o["syn_wav_list"][0].shape[0] == (int(osec * 16000) // 1280) * 1280
+                others[tag] = {"value": round(ob * osec * osteps / el, 1), "unit": "audio-s/s", "ms_per_step": round(1e3 * el / osteps, 3),
+                               "steps": osteps, "roofline": roofline_of(otimer.summary(), 1e3 * el / osteps, 1, brief=True)}
+                del mdl, w, o
+                torch.cuda.empty_cache()
+            except Exception as e:  # an extra: never fails the bench line
+                ops.PROFILER = None
+                others[tag] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         via = "RCCL point-to-point (xGMI)" if backend == "nccl" else f"{backend} through host memory (REHEARSAL on shared cards, not the metric)"
@@ -352,35 +520,18 @@ def main():
         if dist_note:
             line["note"] = dist_note
         if timer is not None:
-            summ = timer.summary()
-            if summ:
-                step_ms = 1e3 * el_main / args.steps
-                kind = max(summ, key=lambda k: summ[k]["ms"])
-                d = summ[kind]
-                ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-                traffic, src = pmc_traffic(kind)
-                tot_ms = sum(v["ms"] for v in summ.values())
-                tot_fl = sum(v["flops"] for v in summ.values())
-                line["roofline"] = {
-                    "bound": "mfma", "kernel": {"convnext_bf16": "swc_convnext_mlp (bf16)"}.get(kind, f"swc_gemm ({kind})"),
-                    "achieved": round(ach, 2), "peak": round(PEAK_TFLOPS[kind], 1), "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_TFLOPS[kind], 4), "traffic": traffic, "traffic_source": src,
-                    "launches_per_step": d["launches"] // n_sampled, "sampled_steps": n_sampled,
-                    "avg_launch_ms": round(d["ms"] / d["launches"], 4),
-                    "share_of_step": round(d["ms"] / n_sampled / step_ms, 3),
-                    "other": {k: {"TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                  "frac": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_TFLOPS[k], 4),
-                                  "launches_per_step": v["launches"] // n_sampled,
-                                  "share_of_step": round(v["ms"] / n_sampled / step_ms, 3)}
-                              for k, v in summ.items() if k != kind},
-                    "all_mfma_kernels": {"TFLOP/s": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
-                                         "share_of_step": round(tot_ms / n_sampled / step_ms, 3)},
-                    "commit": git_commit(),
-                }
-        if world == 1 and args.cpu_baseline != "off":
-            threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-            shapes = [2] if args.cpu_baseline == "sample" else [8, 32]
-            line["cpu_baseline"] = cpu_baseline(gp, sd, shapes, args.seconds, threads)
+            rf = roofline_of(timer.summary(), 1e3 * el_main / args.steps, n_sampled)
+            if rf:
+                line["roofline"] = rf
+        if parity:
+            line["parity"] = parity
+        if others is not None:
+            line["other_configs"] = others
+        if cpu_res is not None:
+            if args.cpu_baseline == "sample":
+                cpu_res["full_shapes"] = ("B = 8 and B = 32 x 10 s (BASELINE.md 2) with `--cpu-baseline full`: "
+                                          "profiles/r02_cpu_baseline_full.json (5.37 / 5.65 audio-s/s, 16 threads, EPYC 9575F)")
+            line["cpu_baseline"] = cpu_res
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

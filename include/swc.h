@@ -49,8 +49,10 @@ extern "C" {
 #define SWC_F16S_ACT_SCALE 64.0f
 /*
  * SWC_FP8 — OCP e4m3fn bytes (gfx950's native fp8; max 448, 3 mantissa bits), one byte per element, for the
- * "fp8 Whisper-encoder GEMMs" preset (BASELINE.json configs[4]): swc_gemm contracts two fp8 operands with
- * v_mfma_f32_16x16x32_fp8_fp8 (f32 accumulate).  Values are stored pre-multiplied by a power of two chosen by
+ * "fp8 Whisper-encoder GEMMs" preset (BASELINE.json configs[4]): swc_gemm contracts two fp8 operands with the
+ * block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 (e4m3 x e4m3, K = 128 per instruction, f32 accumulate: twice the bf16
+ * rate per clock; the non-scaled v_mfma_f32_16x16x32_fp8_fp8 runs at the bf16 rate and is not used).  Values are stored
+ * pre-multiplied by a power of two chosen by
  * the caller (activations: SWC_FP8_ACT_SCALE; weights: per tensor) and un-done by `alpha`; conversions saturate
  * at +-448.  This preset trades the bit-exact indices for speed: its tolerance is stated in DESIGN.md section 4.
  */

@@ -156,11 +156,15 @@ def main_distributed(args, world):
     ngpu = torch.cuda.device_count()
     device = torch.device("cuda", local % max(ngpu, 1))
     torch.cuda.set_device(device)
+    import datetime
+    # a failed peer must not leave the others waiting for the default 10 minutes (failures of the local work are made
+    # collective by DataParallelCodec itself; this bounds what is left: a rank that dies)
+    tmo = datetime.timedelta(seconds=240)
     if args.dist_backend == "nccl":
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl", device_id=device, timeout=tmo)
         comm = None
     else:
-        dist.init_process_group(args.dist_backend)
+        dist.init_process_group(args.dist_backend, timeout=tmo)
         comm = "cpu"
     try:
         generator = load_model(args, device)

@@ -60,13 +60,19 @@ def _on_model_device(fn):
         if id(self) in active:  # an entry point called from another one (encode -> inference_tokenize) on this thread:
             return fn(self, *a, **k)  # the outer guard is in force (current device, counter pointer are per thread)
         with torch.cuda.device(dev):
-            ops.set_saturation_counter(self._sat_state(dev)["buf"])
+            # the counter pointer is per calling thread: a call into a second model from inside this one's entry point
+            # (or around it) must find ITS counter again afterwards, or its later kernels would go uncounted
+            prev = getattr(_TLS, "counter", None)
+            buf = self._sat_state(dev)["buf"]
+            ops.set_saturation_counter(buf)
+            _TLS.counter = buf
             active.add(id(self))
             try:
                 return fn(self, *a, **k)
             finally:
                 active.discard(id(self))
-                ops.set_saturation_counter(None)
+                ops.set_saturation_counter(prev)
+                _TLS.counter = prev
     return wrapped
 
 
@@ -336,12 +342,18 @@ class AudioCodec(nn.Module):
         if origin is None:
             with AudioCodec._REPACK_LOCK:
                 if self._precision != p:
-                    self.precision = p
+                    if self._packed_file is not None:
+                        # a packed-operand file holds no f32 weights to pack from: it carries the exact-f32 encoder
+                        # operands of its fallback preset beside the split-f16 ones (export_packed); adopt those
+                        self._precision = p
+                        self._pk = None
+                    else:
+                        self.precision = p
                 self._packed()
             return
         with AudioCodec._REPACK_LOCK:
             if origin._precision != p:
-                origin.precision = p
+                origin._switch_precision(p)
             P = origin._packed()
         self._precision, self._pk, self._pk_key = p, P, origin._pk_key
 
@@ -379,22 +391,49 @@ class AudioCodec(nn.Module):
         e, d = PRECISIONS[self._precision]
         return _TORCH_DT[e], _TORCH_DT[d]
 
+    # encode-side operand fields of _Packed that depend on the encode operand type: what a packed-operand file stores a
+    # second time, in exact f32, for the range-guard fallback (mixed -> mixed_f32)
+    _ENCODE_FIELDS = ("edt", "c1dt", "c1w", "c1b", "c2w", "c2b", "enc_ldt", "enc_layers", "enc_ln", "inw", "inb",
+                      "down_units", "tlw", "tlb")
+    _FALLBACK_OF = {"mixed": "mixed_f32"}
+
     def _packed(self):
-        dev = self._buffers_device()
-        if dev.type != "cuda":
-            raise SwcError("AudioCodec runs on the HIP device only (call .to('cuda')); there is no CPU fallback")
-        key = (dev, self._precision)
-        if self._pk is not None and self._pk_key == key:
+        # under the lock: the range-guard fallback of another thread (a batch in flight on a replica) replaces the
+        # (preset, operands) pair of this object while inference_detokenize / forward of this thread fetch it
+        with AudioCodec._REPACK_LOCK:
+            dev = self._buffers_device()
+            if dev.type != "cuda":
+                raise SwcError("AudioCodec runs on the HIP device only (call .to('cuda')); there is no CPU fallback")
+            key = (dev, self._precision)
+            if self._pk is not None and self._pk_key == key:
+                return self._pk
+            if self._packed_file is not None:
+                self._pk = self._load_packed_file(dev)
+            else:
+                self._pk = self._pack(dev)
+            self._pk_key = key
             return self._pk
-        if self._packed_file is not None:
-            self._pk, meta = packed.load(self._packed_file, dev, _PACK_CLASSES)
-            if meta["precision"] != self._precision or meta["abi"] != ops.abi_version():
-                raise SwcError(f"{self._packed_file}: packed for precision {meta['precision']} / library ABI {meta['abi']}, "
-                               f"this is {self._precision} / {ops.abi_version()}: pack the checkpoint again")
-        else:
-            self._pk = self._pack(dev)
-        self._pk_key = key
-        return self._pk
+
+    def _load_packed_file(self, dev):
+        """operands of a packed-operand file for the CURRENT preset: the preset it was packed for, or that preset's
+        range-guard fallback (exact-f32 encoder operands stored in the same file, loaded only when needed)."""
+        P, meta = packed.load(self._packed_file, dev, _PACK_CLASSES)
+        if meta["abi"] != ops.abi_version():
+            raise SwcError(f"{self._packed_file}: packed for library ABI {meta['abi']}, this is {ops.abi_version()}: "
+                           "pack the checkpoint again")
+        if meta["precision"] == self._precision:
+            return P
+        if self._FALLBACK_OF.get(meta["precision"]) == self._precision:
+            fb = packed.load_extra(self._packed_file, dev, _PACK_CLASSES, "fallback_encode")
+            if fb is None:
+                raise SwcError(f"split-f16 operands clipped, and {self._packed_file} carries no exact-f32 fallback operands "
+                               f"(written by an older tools/pack_checkpoint.py): pack the checkpoint again, pack it for "
+                               f"precision={self._precision!r}, or load the .pt")
+            for k in self._ENCODE_FIELDS:
+                setattr(P, k, fb[k])
+            return P
+        raise SwcError(f"{self._packed_file}: packed for precision {meta['precision']}, this is {self._precision}: "
+                       "pack the checkpoint again")
 
     _TUNABLES = ("saturation_policy", "varlen_packing", "length_bucketing", "bucket_overhead_tokens", "trim_vocos", "ragged_vocos",
                  "vocos_streams", "vocos_phase_us", "vocos_split_override", "max_rows_per_call", "fused_mlp_min_rows")
@@ -418,9 +457,23 @@ class AudioCodec(nn.Module):
         """Write this model's GEMM-ready operands (current precision preset, current device) to a packed-operand
         .safetensors file that load_from_checkpoint() maps straight to the device (tools/pack_checkpoint.py --fold)."""
         P = self._packed()
-        torch.cuda.synchronize(self._buffers_device())
-        meta = {"precision": self._precision, "config": _config_digest(self.generator_params), "abi": ops.abi_version()}
-        return packed.save(path, P, _PACK_CLASSES, meta)
+        dev = self._buffers_device()
+        extra = {}
+        fb = self._FALLBACK_OF.get(self._precision)
+        if fb is not None and self._packed_file is None:
+            # the exact-f32 encoder operands the range guard falls back to when split-f16 activations clip (trained
+            # Whisper-style outlier channels): stored beside the preset's own, read only if that ever happens
+            keep = (self._precision, self._pk, self._pk_key)
+            try:
+                self._precision, self._pk = fb, None
+                Pf = self._pack(dev)
+            finally:
+                self._precision, self._pk, self._pk_key = keep
+            extra["fallback_encode"] = {k: getattr(Pf, k) for k in self._ENCODE_FIELDS}
+        torch.cuda.synchronize(dev)
+        meta = {"precision": self._precision, "config": _config_digest(self.generator_params), "abi": ops.abi_version(),
+                "fallback": fb if extra else None}
+        return packed.save(path, P, _PACK_CLASSES, meta, extra=extra)
 
     @torch.no_grad()
     def _pack(self, dev):
@@ -548,6 +601,10 @@ class AudioCodec(nn.Module):
             if P.fused_mlp:
                 blk = P.blocks[-1]
                 blk["ws"] = ops.convnext_pack(blk["w1"].w, blk["w2"].w)
+        # frames a kept sample can depend on: embed k7 (+-3), one depthwise k7 per block (+-3 each), ISTFT overlap (+-3)
+        if self.VOCOS_HALO_FRAMES < 3 * (v["num_layers"] + 1) + 3:
+            raise SwcError(f"VOCOS_HALO_FRAMES = {self.VOCOS_HALO_FRAMES} is too small for {v['num_layers']} ConvNeXt blocks "
+                           "(halo-trimmed / tile-skipping Vocos would no longer be bit-exact)")
         P.vfin = (V(sd[p + "final_layer_norm.weight"]), V(sd[p + "final_layer_norm.bias"]))
         P.hw, P.hb = W(sd["vocos.head.out.weight"], ddt), V(sd["vocos.head.out.bias"])
         win = sd["vocos.head.istft.window"].float()
@@ -767,7 +824,10 @@ class AudioCodec(nn.Module):
         # one fused kernel per block when the grid fills the chip (128-frame tiles, one per CU); small batches keep the
         # two-GEMM form, whose 128 x 128 tiles spread over more CUs
         fused = P.fused_mlp and M >= self.fused_mlp_min_rows
-        x2 = torch.empty_like(x) if fused else None  # the fused block is not in place: two buffers alternate
+        # the fused block is not in place: two buffers alternate.  With per-row limits the skipped tiles are never
+        # written: zero-filled once, so that what lies beyond a row's limit is deterministic (the reference zero-fills
+        # beyond the valid length, model.py:356-360) instead of uninitialised memory
+        x2 = (torch.zeros_like(x) if limits is not None else torch.empty_like(x)) if fused else None
         lim_dev = self._dev_ints(limits, mel.device) if (fused and limits is not None) else None
         split = self._vocos_split(B, Tv) if (fused and lim_dev is None) else None
         if split is not None:

@@ -223,7 +223,11 @@ static int read_subframe(br_t* b, int64_t* s, int bs, int bps) {
     if (br_read(b, 1)) return FLAC_E_FORMAT; /* padding bit */
     int type = (int)br_read(b, 6);
     int wasted = 0;
-    if (br_read(b, 1)) wasted = (int)br_unary(b) + 1;
+    if (br_read(b, 1)) {
+        const uint32_t z = br_unary(b); /* a crafted stream may carry more than 2^31 zero bits: compare before the cast */
+        if (z >= (uint32_t)bps - 1u) return FLAC_E_FORMAT;
+        wasted = (int)z + 1;
+    }
     bps -= wasted;
     if (bps <= 0) return FLAC_E_FORMAT;
     int rc = FLAC_OK;

@@ -6,7 +6,13 @@ RCCL group call (its 7 xGMI links work concurrently, nothing is reduced, no ring
 single-GPU codec on its shard, and codes / waveforms are gathered the same way.  This replaces the reference's serial
 batch loop (inference.py:38-64) for batches larger than one GPU's share.
 
-  * Shapes travel as ONE int64 tensor broadcast (count, then lengths) — no pickling, no object collectives.
+  * Shapes travel as ONE fixed-size int64 tensor broadcast ([count, lengths ...], `_INTS_CAP` entries; the maximum code
+    length follows from the lengths on every rank) — no pickling, no object collectives, one host read-back per step.
+  * Failures are collective: after its local work every rank contributes one status int to a MIN all-reduce; if any rank
+    failed (SwcError under policy "raise", out of memory, ...) every rank raises before the gathers are posted, instead
+    of the healthy ranks blocking in a receive that will never be matched.
+  * Per encode_decode() step the collectives are therefore: 1 broadcast (lengths), 1 all-reduce (status, 8 bytes),
+    and the point-to-point scatter + two gathers (batch_isend_irecv groups).
   * Rank 0 assembles the padded [B, L] batch once (one gather kernel) and sends each rank its ROW SLICE of that
     buffer: no per-shard concatenation, no staging copy.  Receivers use row views of what arrives.
   * The only global quantity is the decode padding length: the reference's un-masked up-sampler / Vocos make a short
@@ -65,25 +71,56 @@ class DataParallelCodec:
         self.world = dist.get_world_size(group)
 
     # ------------------------------------------------------------------ small integers: one tensor broadcast
+    _INTS_CAP = 1024  # entries of the fixed-size broadcast (8 KiB): count + up to 1023 lengths in ONE collective
+
     def _share_ints(self, values):
-        """rank 0 passes a list of ints; every rank returns it (two int64 broadcasts: count, payload)."""
+        """rank 0 passes a list of ints; every rank returns it.  One int64 broadcast of fixed size ([count, values ...]) and
+        one host read-back; lists longer than the buffer take a second broadcast for the remainder."""
         if self.world == 1:
             return [int(v) for v in values]
-        n = torch.tensor([len(values) if self.rank == 0 else 0], dtype=torch.int64, device=self.comm)
-        dist.broadcast(n, src=0, group=self.group)
-        k = int(n.item())
-        t = torch.tensor(list(values), dtype=torch.int64, device=self.comm) if self.rank == 0 else \
-            torch.empty(k, dtype=torch.int64, device=self.comm)
-        if k:
-            dist.broadcast(t, src=0, group=self.group)
-        return [int(v) for v in t.tolist()]
+        cap = self._INTS_CAP
+        if self.rank == 0:
+            vals = [int(v) for v in values]
+            head = [len(vals)] + vals[: cap - 1]
+            t = torch.tensor(head + [0] * (cap - len(head)), dtype=torch.int64, device=self.comm)
+        else:
+            t = torch.empty(cap, dtype=torch.int64, device=self.comm)
+        dist.broadcast(t, src=0, group=self.group)
+        got = t.tolist()
+        k = int(got[0])
+        out = got[1: 1 + min(k, cap - 1)]
+        if k > cap - 1:
+            rest = torch.tensor(vals[cap - 1:], dtype=torch.int64, device=self.comm) if self.rank == 0 else \
+                torch.empty(k - (cap - 1), dtype=torch.int64, device=self.comm)
+            dist.broadcast(rest, src=0, group=self.group)
+            out += rest.tolist()
+        return [int(v) for v in out]
 
-    def _global_max(self, v):
-        if self.world == 1:
-            return int(v)
-        t = torch.tensor([int(v)], dtype=torch.int64, device=self.comm)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        return int(t.item())
+    def _agree(self, error):
+        """Collective failure handling: every rank passes the exception its local work raised (or None).  If any rank
+        failed, EVERY rank raises here — the failing one its own exception, the others a RuntimeError naming the situation —
+        before another collective or point-to-point call is posted."""
+        if self.world > 1:
+            t = torch.tensor([0 if error is not None else 1], dtype=torch.int64, device=self.comm)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            ok = int(t.item()) == 1
+        else:
+            ok = error is None
+        if error is not None:
+            raise error
+        if not ok:
+            raise RuntimeError("DataParallelCodec: another rank failed in its local encode / decode; this step is abandoned "
+                               "on every rank")
+
+    def _guarded(self, fn):
+        """fn() = this rank's local work; returns its result after all ranks have agreed that nobody failed."""
+        err, out = None, None
+        try:
+            out = fn()
+        except Exception as e:  # noqa: BLE001 - re-raised by _agree on this rank, reported on the others
+            err = e
+        self._agree(err)
+        return out
 
     # ------------------------------------------------------------------ point-to-point scatter / gather of row slices
     def _scatter_rows(self, batch, parts, width, dtype):
@@ -125,9 +162,9 @@ class DataParallelCodec:
         a, b = parts[self.rank]
         works = []
         if b > a and width > 0:
-            src = mine if mine.device == self.comm else mine.to(self.comm)
-            works = dist.batch_isend_irecv([dist.P2POp(dist.isend, src.contiguous(), 0, self.group)])
-            return _Pending(works, [src])
+            src = (mine if mine.device == self.comm else mine.to(self.comm)).contiguous()
+            works = dist.batch_isend_irecv([dist.P2POp(dist.isend, src, 0, self.group)])
+            return _Pending(works, [src])  # the very tensor being sent stays referenced until wait()
         return _Pending(works, [])
 
     # ------------------------------------------------------------------ batch assembly helpers
@@ -146,14 +183,6 @@ class DataParallelCodec:
             if lens[i]:
                 out[i, : lens[i]] = t.reshape(-1).to(self.device, dtype)
         return out
-
-    def _local_encode(self, wav_list, lens, parts, overlap_seconds):
-        """scatter + this rank's encode (see _encode_rows)."""
-        L = max(lens) if lens else 0
-        batch = self._pad_batch(wav_list, lens, torch.float32) if self.rank == 0 else None
-        mine = self._scatter_rows(batch, parts, max(L, 1) if lens else 0, torch.float32)
-        a, b = parts[self.rank]
-        return self._encode_rows(mine, lens, a, b, overlap_seconds)
 
     def _encode_rows(self, mine, lens, a, b, overlap_seconds):
         """this rank's encode of its received rows.  Returns the codes as a padded (G, rows, Lc') tensor (codecs with the
@@ -231,7 +260,11 @@ class DataParallelCodec:
         if not lens:
             return {"codes_list": []} if self.rank == 0 else None
         parts = partition(lens, self.world)
-        codes = self._local_encode(wav_list, lens, parts, overlap_seconds)
+        L = max(lens)
+        batch = self._pad_batch(wav_list, lens, torch.float32) if self.rank == 0 else None
+        mine = self._scatter_rows(batch, parts, max(L, 1), torch.float32)
+        a, b = parts[self.rank]
+        codes = self._guarded(lambda: self._encode_rows(mine, lens, a, b, overlap_seconds))
         rate = self.codec.encoder_downsample_rate
         clen = [l // rate for l in lens]
         Lc = max(max(clen), 1)
@@ -265,7 +298,7 @@ class DataParallelCodec:
             local = mine.view(b - a, G, Lc).permute(1, 0, 2) if b > a else None  # (G, rows, Lc) view of the received rows
         else:
             local = [mine[(i - a) * G:(i - a + 1) * G, : clen[i]] for i in range(a, b)]
-        rows = self._local_decode(local, clen, a, b, t_max, overlap_seconds, Lw)
+        rows = self._guarded(lambda: self._local_decode(local, clen, a, b, t_max, overlap_seconds, Lw))
         got = self._gather_rows_async(rows, parts, Lw, torch.float32).wait()
         if self.rank != 0:
             return None
@@ -296,13 +329,14 @@ class DataParallelCodec:
         # the operand-range check of the split-f16 encoder is read back ONCE, after the decode has been enqueued (no stall
         # between encode and decode); if operands clipped the codec has switched to exact-f32 operands and the shard is redone
         defer = getattr(self.codec, "deferred_range_check", None)
-        if defer is not None:
+
+        def guarded_round_trip():
+            if defer is None:
+                return local_round_trip()
             with defer() as chk:
-                codes, rows = local_round_trip()
-            if chk.clipped:
-                codes, rows = local_round_trip()
-        else:
-            codes, rows = local_round_trip()
+                out = local_round_trip()
+            return local_round_trip() if chk.clipped else out
+        codes, rows = self._guarded(guarded_round_trip)
         pend_codes = self._gather_rows_async(self._codes_rows(codes, clen, a, b, Lc), cparts, Lc, torch.int32)
         pend_wavs = self._gather_rows_async(rows, parts, Lw, torch.float32)
         got_c = pend_codes.wait()

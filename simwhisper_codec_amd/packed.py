@@ -15,7 +15,7 @@ import json
 
 import torch
 
-FORMAT = "simwhisper-codec packed operands v1"
+FORMAT = "simwhisper-codec packed operands v1"  # optional parts ("extra") are additional skeletons in the metadata
 _DT = {"float32": torch.float32, "bfloat16": torch.bfloat16, "float16": torch.float16,
        "float8_e4m3fn": torch.float8_e4m3fn, "int32": torch.int32, "int64": torch.int64, "uint8": torch.uint8}
 
@@ -79,12 +79,29 @@ def unflatten(skel, get_tensor, classes):
     return build(skel)
 
 
-def save(path, packed, classes, meta):
+def save(path, packed, classes, meta, extra=None):
+    """extra: {part name: object} stored beside the main operands under their own skeletons (tensor names prefixed with the
+    part name); load() never touches them, load_extra() reads one part."""
     from safetensors.torch import save_file
     skel, tensors = flatten(packed, classes)
     md = {"format": FORMAT, "skeleton": json.dumps(skel), "meta": json.dumps(meta)}
+    for part, obj in (extra or {}).items():
+        sk, ts = flatten(obj, classes)
+        ren = {old: f"{part}.{old}" for old in ts}
+        md[f"skeleton.{part}"] = json.dumps(_rename(sk, ren))
+        tensors.update({ren[k]: v for k, v in ts.items()})
     save_file(tensors, path, metadata=md)
     return len(tensors), sum(t.numel() * t.element_size() for t in tensors.values())
+
+
+def _rename(skel, ren):
+    if isinstance(skel, list):
+        return [_rename(v, ren) for v in skel]
+    if isinstance(skel, dict):
+        if "__t__" in skel:
+            return dict(skel, __t__=ren[skel["__t__"]])
+        return {k: _rename(v, ren) for k, v in skel.items()}
+    return skel
 
 
 def peek(path):
@@ -95,6 +112,16 @@ def peek(path):
     if md.get("format") != FORMAT:
         return None
     return json.loads(md["meta"])
+
+
+def load_extra(path, device, classes, part):
+    """the object stored under `part` by save(..., extra=...), tensors on `device`; None if the file has no such part"""
+    from safetensors import safe_open
+    with safe_open(path, framework="pt", device=str(device)) as f:
+        md = f.metadata() or {}
+        if md.get("format") != FORMAT or f"skeleton.{part}" not in md:
+            return None
+        return unflatten(json.loads(md[f"skeleton.{part}"]), f.get_tensor, classes)
 
 
 def load(path, device, classes):

@@ -113,13 +113,17 @@ def _decode_flac(path):
     rc = lib.swc_flac_info(data, len(data), C.byref(sr), C.byref(ch), C.byref(bits), C.byref(total))
     if rc != 0:
         raise ValueError(f"{path}: {_FLAC_ERRORS.get(rc, rc)}")
-    cap = int(total.value) or int(lib.swc_flac_max_samples(len(data)))
+    # STREAMINFO's 36-bit sample count is not trusted for the allocation (a crafted header would ask for 256 GiB): start
+    # from what the file's size makes plausible and grow on FLAC_E_SPACE up to the declared (or, undeclared, a hard) bound
+    guess = int(lib.swc_flac_max_samples(len(data)))
+    limit = int(total.value) if total.value else (1 << 31)
+    cap = max(1, min(limit, guess))
     md5 = C.c_int32(0)
     while True:
         out = np.empty((cap, ch.value), dtype=np.int32)
         n = lib.swc_flac_decode(data, len(data), out.ctypes.data_as(C.c_void_p), cap, C.byref(md5))
-        if n == -4 and not total.value and cap < (1 << 31):  # length unknown: grow
-            cap *= 4
+        if n == -4 and cap < limit:  # constant / highly compressible audio can exceed the first guess: grow
+            cap = min(limit, cap * 4)
             continue
         break
     if n < 0:

@@ -42,6 +42,7 @@ def _free_port():
 
 def _worker(rank, world, port, lens, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         codec = FakeCodec()
@@ -66,7 +67,9 @@ def _worker(rank, world, port, lens, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,lens", [(2, [5000, 12800, 3000, 40000, 1280]), (3, [2560, 2560]), (2, [1000])])
+@pytest.mark.parametrize("world,lens", [(2, [5000, 12800, 3000, 40000, 1280]), (3, [2560, 2560]), (2, [1000]),
+                                        # the 8-GPU node's layout (BASELINE.json configs[3]: 256 utterances, 32 per rank), short rows
+                                        (8, [2560 + 1280 * (i % 3) for i in range(256)])])
 def test_sharded_equals_unsharded(world, lens):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
@@ -88,3 +91,77 @@ def test_partition_properties():
         assert all(a <= b for a, b in parts)
     parts = partition([1] * 256, 8)
     assert [b - a for a, b in parts] == [32] * 8
+
+
+class _FailingCodec(FakeCodec):
+    """raises on one rank only: the others must not be left inside a receive that is never matched"""
+
+    def __init__(self, bad_rank):
+        self.bad_rank = bad_rank
+
+    def encode(self, wav_list, overlap_seconds=10, device=None):
+        if dist.get_rank() == self.bad_rank:
+            raise ValueError("this rank's shard failed")
+        return super().encode(wav_list, overlap_seconds, device)
+
+
+def _worker_fail(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        dp = DataParallelCodec(_FailingCodec(bad_rank=1), "cpu")
+        g = torch.Generator().manual_seed(0)
+        wavs = [torch.randn(n, generator=g) for n in [5000, 12800, 3000, 6000, 7000, 2560]] if rank == 0 else None
+        seen = []
+        for call in (dp.encode, dp.encode_decode):
+            try:
+                call(wavs)
+                seen.append("no error")
+            except ValueError as e:
+                seen.append(f"own:{e}")
+            except RuntimeError as e:
+                seen.append("other" if "another rank failed" in str(e) else f"unexpected:{e}")
+        # the group is still usable: every rank raised at the same point, no collective was left half done
+        ok = dp.decode([torch.zeros(8, 3, dtype=torch.int32)] * 4 if rank == 0 else None)
+        ret.put((rank, seen, (ok is not None) == (rank == 0)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_failing_rank_fails_every_rank_together():
+    """a rank that raises in its local encode must not strand the others in point-to-point waits: after the local
+    work a status all-reduce makes every rank raise before the gathers are posted (dist.py `_agree`)."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fail, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(ret.get(timeout=5) for _ in range(world))
+    for rank, seen, usable in got:
+        want = "own:this rank's shard failed" if rank == 1 else "other"
+        assert seen == [want, want], (rank, seen)
+        assert usable
+
+
+def test_share_ints_is_one_broadcast(monkeypatch):
+    """lengths travel in ONE fixed-size broadcast (count + values): one collective, one host read-back per step."""
+    class _DP(DataParallelCodec):
+        def __init__(self):
+            self.world, self.rank, self.group, self.comm = 2, 0, None, torch.device("cpu")
+    calls = []
+    monkeypatch.setattr(dist, "broadcast", lambda t, src=0, group=None: calls.append(t.numel()))
+    dp = _DP()
+    assert dp._share_ints(list(range(7, 300))) == list(range(7, 300))
+    assert calls == [DataParallelCodec._INTS_CAP]
+    calls.clear()
+    big = list(range(3000))
+    assert dp._share_ints(big) == big and len(calls) == 2   # beyond the buffer: one more for the remainder
+    calls.clear()
+    assert dp._share_ints([]) == [] and len(calls) == 1

@@ -126,3 +126,29 @@ def test_flac_decoder_survives_damaged_streams(tmp_path):
             bad += 1
     assert bad > 250 and ok + bad == 400
 
+
+
+def test_flac_crafted_header_cannot_demand_memory(tmp_path, monkeypatch):
+    """STREAMINFO's 36-bit sample count is not trusted for the output allocation.  A header that claims 2^36 - 1
+    samples per channel (a 256 GiB buffer if believed) is decoded into buffers sized by the file, and rejected because the
+    stream ends early; constant audio, which really does exceed the first size guess, still decodes (the buffer grows)."""
+    x = _signal(4096, 1, 16, seed=5)
+    raw = bytearray(fe.encode(x, 16000, 16, blocksize=1024, plan=lambda fi, c: dict(kind=("fixed", 2), porder=1) if c is not None else 0))
+    assert raw[:4] == b"fLaC"
+    q = 8  # STREAMINFO body starts after "fLaC" + 4-byte block header; total samples = low nibble of q[13] + q[14..17]
+    raw[q + 13] |= 0x0F
+    raw[q + 14:q + 18] = b"\xff\xff\xff\xff"
+    p = tmp_path / "crafted.flac"
+    p.write_bytes(bytes(raw))
+    biggest = []
+    real_empty = np.empty
+    monkeypatch.setattr(np, "empty", lambda shape, *a, **k: (biggest.append(int(np.prod(shape))), real_empty(shape, *a, **k))[1])
+    with pytest.raises(ValueError):
+        wavio._decode_flac(str(p))
+    assert max(biggest) <= 64 * (16 * len(raw) + 65536)          # a few growth steps from the file-size guess, never 2^36
+    biggest.clear()
+    z = np.zeros((3_000_000, 1), dtype=np.int64)                 # 3 M samples of silence in a few hundred bytes
+    pz = tmp_path / "silence.flac"
+    pz.write_bytes(fe.encode(z, 16000, 16, blocksize=4096, plan=lambda fi, c: dict(kind="constant") if c is not None else 0))
+    pcm, sr, bits = wavio._decode_flac(str(pz))
+    assert pcm.shape == (3_000_000, 1) and not pcm.any() and len(biggest) >= 2   # the buffer grew at least once

@@ -259,3 +259,80 @@ def test_deferred_range_check_redo():
     with m2.deferred_range_check() as chk3:
         m2.decode(m2.encode(dw)["codes_list"])
     assert not chk3.clipped and m2.precision == "mixed"
+
+
+def test_packed_outlier_checkpoint_falls_back(tmp_path, caplog):
+    """The deployment case of the range guard: an outlier checkpoint shipped as a packed-operand file (`export_packed` /
+    tools/pack_checkpoint.py --fold, preset `mixed`).  The file carries the exact-f32 encoder operands of the fallback
+    preset beside the split-f16 ones; when the encode clips, the model adopts them (no f32 weights exist to pack from)
+    and returns the reference's codes — also from a replica running beside its origin (pipeline.InFlight)."""
+    import yaml
+    from audiocodec.model import AudioCodec
+    from oracle.ref_cpu import Oracle
+    from simwhisper_codec_amd import packed, synth
+    from simwhisper_codec_amd.pipeline import InFlight
+    tag = "tiny"
+    sd = _outlier_state_dict(tag)
+    wavs = [synth.synth_audio(30000, index=300, kind="speech"), synth.synth_audio(21111, index=301, kind="noise")]
+    want = Oracle(PARAMS[tag](), sd).encode(wavs, trim=True)["codes_list"]
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(yaml.safe_dump({"generator_params": PARAMS[tag]()}))
+    path = str(tmp_path / "outlier.mixed.safetensors")
+    src = _model(tag, "mixed", sd)
+    src.export_packed(path)
+    assert src.precision == "mixed"                       # exporting the fallback operands did not switch the source
+    assert packed.peek(path)["fallback"] == "mixed_f32"
+    dw = [w.to(DEV) for w in wavs]
+    m = AudioCodec.load_from_checkpoint(str(cfg), path).to(DEV).eval()
+    assert m.precision == "mixed" and len(list(m.buffers())) == 1
+    with caplog.at_level(logging.WARNING):
+        got = m.encode(dw)["codes_list"]
+    assert m.precision == "mixed_f32" and "clipped" in caplog.text
+    for a, b in zip(got, want):
+        assert torch.equal(a.cpu().long(), b.long())
+    wav = m.decode(got)["syn_wav_list"]                    # the decode side of the file is untouched by the switch
+    ref = src.decode([c.to(DEV) for c in want])["syn_wav_list"]
+    for a, b in zip(wav, ref):
+        assert torch.equal(a, b)
+    # replicas of a packed-file model follow the same way
+    m2 = AudioCodec.load_from_checkpoint(str(cfg), path).to(DEV).eval()
+    with InFlight(m2, 2) as pipe:
+        outs = pipe.map(lambda mdl, w: mdl.encode(w)["codes_list"], [dw] * 4)
+        outs += [mm.encode(dw)["codes_list"] for mm in pipe.models]
+        assert all(mm.precision == "mixed_f32" for mm in pipe.models)
+    for got in outs:
+        for a, b in zip(got, want):
+            assert torch.equal(a.cpu().long(), b.long())
+    # a file without the fallback part (older writer): the clip is reported as such, not as a packing mismatch
+    P = src._packed()
+    old = str(tmp_path / "old.safetensors")
+    from simwhisper_codec_amd.codec import _PACK_CLASSES, _config_digest
+    from simwhisper_codec_amd import ops
+    from simwhisper_codec_amd._lib import SwcError
+    packed.save(old, P, _PACK_CLASSES, {"precision": "mixed", "config": _config_digest(PARAMS[tag]()), "abi": ops.abi_version()})
+    m3 = AudioCodec.load_from_checkpoint(str(cfg), old).to(DEV).eval()
+    with pytest.raises(SwcError, match="clipped"):
+        m3.encode(dw)
+
+
+def test_nested_models_keep_their_range_counters():
+    """_on_model_device restores the calling thread's counter pointer: a call into a second model from inside (or between)
+    calls of a first one must not leave the first one's later kernels uncounted."""
+    from simwhisper_codec_amd import synth
+    tag = "tiny"
+    sd = _outlier_state_dict(tag)
+    a = _model(tag, "mixed", sd)
+    a.saturation_policy = "ignore"
+    b = _model(tag, "mixed")
+    w = [synth.synth_audio(30000, index=300, kind="speech").to(DEV)]
+    real = a._encode_padded
+
+    def nested(*args, **kw):      # model b runs to completion in the middle of a's encode
+        b.encode(w)
+        return real(*args, **kw)
+    a._encode_padded = nested
+    try:
+        a.encode(w)
+    finally:
+        del a._encode_padded
+    assert a.saturation_count()["f16s"] > 0 and b.saturation_count() == {"f16s": 0, "fp8": 0}

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=${1:-$R/gpurun_out/pmc_mfma}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $out/p -o m -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-baseline off --no-timer --no-dist > $out/run.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --output-format csv -d $out/p -o m -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-baseline off --no-timer --no-dist --no-inflight --other-configs off > $out/run.log 2>&1
 cd $R
 python3 tools/pmc_mfma.py $out > $out/mfma_util.json
 cat $out/mfma_util.json

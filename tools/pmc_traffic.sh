@@ -7,8 +7,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=${1:-$R/gpurun_out/pmc_traffic}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-baseline off --no-timer --no-dist > $out/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-baseline off --no-timer --no-dist > $out/write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/fetch -o f -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-baseline off --no-timer --no-dist --no-inflight --other-configs off > $out/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/write -o w -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-baseline off --no-timer --no-dist --no-inflight --other-configs off > $out/write.log 2>&1
 cd $R
 python3 tools/pmc_traffic.py $out > $out/traffic.json
 cat $out/traffic.json
