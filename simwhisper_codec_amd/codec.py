@@ -270,8 +270,10 @@ class AudioCodec(nn.Module):
     def _sat_state(self, dev):
         st = self.__dict__.get("_sat")
         if st is None or st["dev"] != dev:
-            st = {"dev": dev, "buf": torch.zeros(2, dtype=torch.int32, device=dev),
-                  "host": torch.zeros(2, dtype=torch.int32).pin_memory(), "seen": [0, 0], "warned": False}
+            # (not inference tensors, whatever the caller's mode: saturation_count() updates the host copy in place later)
+            with torch.inference_mode(False):
+                st = {"dev": dev, "buf": torch.zeros(2, dtype=torch.int32, device=dev),
+                      "host": torch.zeros(2, dtype=torch.int32).pin_memory(), "seen": [0, 0], "warned": False}
             self.__dict__["_sat"] = st
         return st
 
@@ -1013,11 +1015,12 @@ class AudioCodec(nn.Module):
         are assembled by one gather kernel from an uploaded address list instead of one copy per utterance."""
         L = max(max(lens), 1, int(min_len))
         if (dev.type == "cuda" and dtype in (torch.float32, torch.int32) and len(tensors) <= 65535
-                and all(t.device == dev and t.dtype == dtype and t.is_contiguous() and t.data_ptr() % 4 == 0
-                        for t in tensors)):
-            ptrs = self._dev_ints([t.data_ptr() for t in tensors], dev, torch.int64, cache_it=False)
-            nbytes = self._dev_ints([4 * n for n in lens], dev, torch.int64)
-            return ops.gather_rows(ptrs, nbytes, len(tensors), L, dtype, dev)
+                and all(t.dtype == dtype and t.device == dev and t.is_contiguous() for t in tensors)):
+            addr = [t.data_ptr() for t in tensors]
+            if not any(a & 3 for a in addr):
+                ptrs = self._dev_ints(addr, dev, torch.int64, cache_it=False)
+                nbytes = self._dev_ints([4 * n for n in lens], dev, torch.int64)
+                return ops.gather_rows(ptrs, nbytes, len(tensors), L, dtype, dev)
         if len(set(lens)) == 1 and lens[0] == L and all(t.device == dev and t.dtype == dtype for t in tensors):
             return torch.stack([t.reshape(-1) for t in tensors])
         out = torch.zeros(len(tensors), L, device=dev, dtype=dtype)

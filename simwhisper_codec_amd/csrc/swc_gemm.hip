@@ -97,12 +97,49 @@ struct GemmP {
     unsigned* sat;   // saturation counter pair of the calling thread (swc_set_saturation_counter) or nullptr
     int kc_per_tap;  // ceil(K / BK)
     int n_tiles_n, n_tiles_m;
+    int nt_mode;     // epilogue stores non-temporal: 0 never, 1 on the LAST tile of a workgroup, 2 always (swc_gemm chooses)
+    int stagger;     // start delay unit in shader cycles: workgroup w starts (w / 8 % 8) * stagger cycles late (0: none)
 };
 
 // Epilogue shared by all geometries.  Transposed product: lane (fr, fh) holds, for activation row
 // 16i + fr of its wave's slab, the 16 contiguous output columns 16fh + 4j + e.
 constexpr int EPI_TP = 68;                       // row pitch (floats) of a wave's transpose block: conflict-free b128 writes
 constexpr int EPI_WAVE_BYTES = 16 * EPI_TP * 4;  // 16 rows x 64 columns per wave
+
+
+// Epilogue stores.  Tuning builds can change how they are issued (tools/build_variant.sh):
+//   -DSWC_ABL_NOSTORE   timing ablation only, WRONG RESULTS: the values are computed and kept live, nothing is stored —
+//                       what a launch would cost if its epilogue stores were free
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// `nt` (wave-uniform): non-temporal store — the line is not kept dirty in the XCD's L2 (see GemmP::nt_mode)
+__device__ __forceinline__ void epi_st128(void* p, unsigned a, unsigned b, unsigned c, unsigned d, bool nt = false) {
+#if defined(SWC_ABL_NOSTORE)
+    asm volatile("" ::"v"(p), "v"(a), "v"(b), "v"(c), "v"(d));
+#else
+    if (nt) __builtin_nontemporal_store((u32x4_t){a, b, c, d}, reinterpret_cast<u32x4_t*>(p));
+    else *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
+#endif
+}
+__device__ __forceinline__ void epi_st128f(void* p, float a, float b, float c, float d, bool nt = false) {
+    epi_st128(p, __float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d), nt);
+}
+__device__ __forceinline__ void epi_st64(void* p, unsigned a, unsigned b, bool nt = false) {
+#if defined(SWC_ABL_NOSTORE)
+    asm volatile("" ::"v"(p), "v"(a), "v"(b));
+#else
+    if (nt) __builtin_nontemporal_store((u32x2_t){a, b}, reinterpret_cast<u32x2_t*>(p));
+    else *reinterpret_cast<uint2*>(p) = make_uint2(a, b);
+#endif
+}
+__device__ __forceinline__ void epi_st32(void* p, unsigned a, bool nt = false) {
+#if defined(SWC_ABL_NOSTORE)
+    asm volatile("" ::"v"(p), "v"(a));
+#else
+    if (nt) __builtin_nontemporal_store(a, reinterpret_cast<unsigned*>(p));
+    else *reinterpret_cast<unsigned*>(p) = a;
+#endif
+}
 
 template <typename OutT>
 __device__ __forceinline__ float epi_act(float x) {
@@ -118,7 +155,7 @@ __device__ __forceinline__ float epi_act(float x) {
 // profiles/r02_gemm_stamps.txt).  Same arithmetic per element, in the same order, as the direct path below.
 template <typename OutT, int MT, bool GELU>
 __device__ __forceinline__ void gemm_epilogue_slab(const GemmP& p, f32x4 (&acc)[MT][4], int row0, int colw, int fr, int fh,
-                                                   float* tbuf, float& amax) {
+                                                   float* tbuf, float& amax, bool nt) {
     int lane = fr + 16 * fh;
     // opaque to the optimiser: everything below depends on it and is therefore computed HERE, once per tile; hoisted out
     // of the persistent tile loop these per-lane addresses stayed live through the K loop, which has no register to spare
@@ -159,15 +196,12 @@ __device__ __forceinline__ void gemm_epilogue_slab(const GemmP& p, f32x4 (&acc)[
                 const float os = p.out_scale;
                 f16s_store4(reinterpret_cast<unsigned short*>(p.C) + (long)row * p.ldc * 2, col, v0 * os, v1 * os, v2 * os, v3 * os, amax);
             } else if constexpr (sizeof(OutT) == 4) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)row * p.ldc + col) = make_float4(v0, v1, v2, v3);
+                epi_st128f(reinterpret_cast<float*>(p.C) + (long)row * p.ldc + col, v0, v1, v2, v3, nt);
             } else if constexpr (sizeof(OutT) == 1) {
                 const float os = p.out_scale;
-                *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(p.C) + (long)row * p.ldc + col) = fp8_pack4(v0 * os, v1 * os, v2 * os, v3 * os, amax);
+                epi_st32(reinterpret_cast<unsigned char*>(p.C) + (long)row * p.ldc + col, fp8_pack4(v0 * os, v1 * os, v2 * os, v3 * os, amax), nt);
             } else {
-                uint2 u;
-                u.x = bf16_pack2(v0, v1);
-                u.y = bf16_pack2(v2, v3);
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (long)row * p.ldc + col) = u;
+                epi_st64(reinterpret_cast<bf16_t*>(p.C) + (long)row * p.ldc + col, bf16_pack2(v0, v1), bf16_pack2(v2, v3), nt);
             }
         }
     }
@@ -177,7 +211,7 @@ __device__ __forceinline__ void gemm_epilogue_slab(const GemmP& p, f32x4 (&acc)[
 // 16fh + 4j + e of its wave's 64-column slab.
 template <typename OutT, int MT, int GELU>  // GELU: 0 none, 1 always, 2 by p.act (one body)
 __device__ __forceinline__ void gemm_epilogue_direct(const GemmP& p, f32x4 (&acc)[MT][4], int bm, int bn, int wr, int wc, int fr,
-                                                     int fh) {
+                                                     int fh, bool nt) {
     OutT* C = reinterpret_cast<OutT*>(p.C);
     const int col0 = bn + wc * 64 + 16 * fh;
     const bool vec_ok = (col0 + 16 <= p.N) && ((p.ldc & (sizeof(OutT) == 1 ? 15 : 3)) == 0) &&
@@ -187,11 +221,23 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmP& p, f32x4 (&acc
     float bv[16], gv[16];
     float amax = 0.f;
     (void)amax;
+    // a lane's 16 columns are 64 contiguous bytes of bias / gamma: four 16-byte loads when they lie inside N (one load and
+    // one branch per column otherwise: 32 dependent-looking scalar loads per tile on the hot GEMMs)
+    if (col0 + 16 <= p.N && ((reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.gamma)) & 15) == 0) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const int col = col0 + c;
-        bv[c] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
-        gv[c] = (p.gamma && col < p.N) ? p.gamma[col] : 1.f;
+        for (int q = 0; q < 4; ++q) {
+            const float4 b4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + col0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 g4 = p.gamma ? *reinterpret_cast<const float4*>(p.gamma + col0 + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+            bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
+            gv[4 * q] = g4.x; gv[4 * q + 1] = g4.y; gv[4 * q + 2] = g4.z; gv[4 * q + 3] = g4.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int col = col0 + c;
+            bv[c] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+            gv[c] = (p.gamma && col < p.N) ? p.gamma[col] : 1.f;
+        }
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -230,8 +276,8 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmP& p, f32x4 (&acc
                 unsigned short* hp = rowp + f16s_col(col0);
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
-                    reinterpret_cast<uint4*>(hp)[q] = make_uint4(h2[4 * q], h2[4 * q + 1], h2[4 * q + 2], h2[4 * q + 3]);
-                    reinterpret_cast<uint4*>(hp + 32)[q] = make_uint4(l2[4 * q], l2[4 * q + 1], l2[4 * q + 2], l2[4 * q + 3]);
+                    epi_st128(reinterpret_cast<uint4*>(hp) + q, h2[4 * q], h2[4 * q + 1], h2[4 * q + 2], h2[4 * q + 3], nt);
+                    epi_st128(reinterpret_cast<uint4*>(hp + 32) + q, l2[4 * q], l2[4 * q + 1], l2[4 * q + 2], l2[4 * q + 3], nt);
                 }
             }
         } else if (vec_ok) {
@@ -247,25 +293,19 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmP& p, f32x4 (&acc
             if constexpr (sizeof(OutT) == 4) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    reinterpret_cast<float4*>(cp)[j] = make_float4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+                    epi_st128f(reinterpret_cast<float4*>(cp) + j, v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3], nt);
             } else if constexpr (sizeof(OutT) == 1) {
                 const float os = p.out_scale;
-                uint4 u;
-                u.x = fp8_pack4(v[0] * os, v[1] * os, v[2] * os, v[3] * os, amax);
-                u.y = fp8_pack4(v[4] * os, v[5] * os, v[6] * os, v[7] * os, amax);
-                u.z = fp8_pack4(v[8] * os, v[9] * os, v[10] * os, v[11] * os, amax);
-                u.w = fp8_pack4(v[12] * os, v[13] * os, v[14] * os, v[15] * os, amax);
-                *reinterpret_cast<uint4*>(cp) = u;
+                const unsigned u0 = fp8_pack4(v[0] * os, v[1] * os, v[2] * os, v[3] * os, amax);
+                const unsigned u1 = fp8_pack4(v[4] * os, v[5] * os, v[6] * os, v[7] * os, amax);
+                const unsigned u2 = fp8_pack4(v[8] * os, v[9] * os, v[10] * os, v[11] * os, amax);
+                const unsigned u3 = fp8_pack4(v[12] * os, v[13] * os, v[14] * os, v[15] * os, amax);
+                epi_st128(cp, u0, u1, u2, u3, nt);
             } else {
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    uint4 u;
-                    u.x = bf16_pack2(v[8 * j + 0], v[8 * j + 1]);
-                    u.y = bf16_pack2(v[8 * j + 2], v[8 * j + 3]);
-                    u.z = bf16_pack2(v[8 * j + 4], v[8 * j + 5]);
-                    u.w = bf16_pack2(v[8 * j + 6], v[8 * j + 7]);
-                    reinterpret_cast<uint4*>(cp)[j] = u;
-                }
+                for (int j = 0; j < 2; ++j)
+                    epi_st128(reinterpret_cast<uint4*>(cp) + j, bf16_pack2(v[8 * j + 0], v[8 * j + 1]), bf16_pack2(v[8 * j + 2], v[8 * j + 3]),
+                              bf16_pack2(v[8 * j + 4], v[8 * j + 5]), bf16_pack2(v[8 * j + 6], v[8 * j + 7]), nt);
             }
         } else {
 #pragma unroll
@@ -286,10 +326,12 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmP& p, f32x4 (&acc
 // The activation is a template parameter behind a wave-uniform branch: as a run-time select inside one body hipcc evaluates
 // the GELU of every element of every GEMM and selects afterwards — the GEMMs without an activation (qkv, out-proj, fc2,
 // pwconv2, every conv) paid 10 (bf16) to 40 (erff) VALU instructions per output for nothing (tools/gemm_stamps.py).
-template <typename OutT, int MT, bool SLAB>
+// ACT: 0 no activation, 1 GELU (both compiled in: one body per kernel — the 16-bit-output plain GEMMs, whose K loops have no
+// register to spare for a second epilogue body), 2 by p.act at run time (wave-uniform branch over two bodies).
+template <typename OutT, int MT, bool SLAB, int ACT>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4], int bm, int bn, int wr, int wc, int fr,
-                                              int fh, float* tbuf) {
-    const bool gelu = p.act == SWC_ACT_GELU;
+                                              int fh, float* tbuf, bool nt) {
+    const bool gelu = ACT == 1 || (ACT == 2 && p.act == SWC_ACT_GELU);
     // f32 outputs (residual stream: out-proj, fc2, pwconv2, heads) take the transposed path: +9 ... +15 % on those GEMMs.
     // 16-bit outputs keep the direct one: a lane's 16 columns are 32 contiguous bytes there, the transposed path measured
     // no faster without and 6 - 8 % slower with the GELU, and split-f16 conversion leaves no register for it
@@ -301,24 +343,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x4 (&acc)[MT][4
                         (!p.residual || (p.ldr & 3) == 0);
         if (__builtin_amdgcn_readfirstlane((int)ok)) {  // wave-uniform by construction
             float amax = 0.f;
-            if (gelu) gemm_epilogue_slab<OutT, MT, true>(p, acc, bm + wr * (MT * 16), colw, fr, fh, tbuf, amax);
-            else gemm_epilogue_slab<OutT, MT, false>(p, acc, bm + wr * (MT * 16), colw, fr, fh, tbuf, amax);
+            if (gelu) gemm_epilogue_slab<OutT, MT, true>(p, acc, bm + wr * (MT * 16), colw, fr, fh, tbuf, amax, nt);
+            else gemm_epilogue_slab<OutT, MT, false>(p, acc, bm + wr * (MT * 16), colw, fr, fh, tbuf, amax, nt);
             if constexpr (__is_same(OutT, fp8_t)) sat_commit(p.sat, 1, amax, SWC_FP8_LIMIT);
             return;
         }
     }
-    if constexpr (__is_same(OutT, f16s_t) && MT == 8) {
-        // the 256-row split-f16 kernel (fc1: always GELU) has no register for two bodies: the K loop spilled
-        gemm_epilogue_direct<OutT, MT, 2>(p, acc, bm, bn, wr, wc, fr, fh);
+    if constexpr (ACT != 2) {
+        gemm_epilogue_direct<OutT, MT, ACT>(p, acc, bm, bn, wr, wc, fr, fh, nt);
+    } else if constexpr (__is_same(OutT, f16s_t) && MT == 8) {
+        // the 256-row split-f16 conv kernel has no register for two bodies (the K loop spilled): one body, GELU by p.act
+        gemm_epilogue_direct<OutT, MT, 2>(p, acc, bm, bn, wr, wc, fr, fh, nt);
     } else {
-        if (gelu) gemm_epilogue_direct<OutT, MT, 1>(p, acc, bm, bn, wr, wc, fr, fh);
-        else gemm_epilogue_direct<OutT, MT, 0>(p, acc, bm, bn, wr, wc, fr, fh);
+        if (gelu) gemm_epilogue_direct<OutT, MT, 1>(p, acc, bm, bn, wr, wc, fr, fh, nt);
+        else gemm_epilogue_direct<OutT, MT, 0>(p, acc, bm, bn, wr, wc, fr, fh, nt);
     }
 }
 
 // PLAIN: one tap, K a multiple of the slice, no stride / padding / row remap — the hot GEMMs.  A separate
 // instantiation so that the implicit-conv bookkeeping (~32 VGPRs) does not sit in the hot loop's register budget.
-template <int MODE, typename OutT, int MT, int WAVES_M, int WAVES_N, bool PLAIN, int RB = 128>
+template <int MODE, typename OutT, int MT, int WAVES_M, int WAVES_N, bool PLAIN, int RB = 128, int ACT = 2>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p) {
     constexpr int ROW_BYTES = RB;  // bytes of K per LDS row per slice: 128, or 64 (bf16 / f32 only: smaller stages, two workgroups per CU)
     constexpr int CPR = RB / 16;   // 16-byte chunks per row
@@ -432,6 +476,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         }
     };
     setup_tile(tl);
+    // De-phasing (multi-tile launches): every workgroup runs the same K loop + epilogue sequence, so all 256 CUs enter
+    // their HBM-bound epilogue together and the matrix pipes of the whole chip idle while the fabric drains 64 MB;
+    // started a fraction of an epilogue apart, the epilogues of one phase group fall into the K loops of the others.
+    if (p.stagger > 0) {
+        const int phase = (blockIdx.x >> 3) & 7;
+        if (phase) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            const unsigned long long wait = (unsigned long long)phase * (unsigned)p.stagger;
+            while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+        }
+    }
     auto stage_slice = [&](int kt, int stage) {
         const unsigned sa = smem_base + stage * STAGE_BYTES + wave_u * 1024;  // one wave-instruction = 1 KiB of rows
         const unsigned sb = sa + A_BYTES;
@@ -618,8 +673,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
 #endif
     // the other stage buffer is free until the fence below (the next tile's first slice goes to stage 0): per-wave scratch
     // (not for 256-row tiles: no register to spare, their K loops spilled or lost their schedule)
-    gemm_epilogue<OutT, MT, MT < 8>(p, acc, bm_done, bn_done, wr, wc, fr, fh,
-                            reinterpret_cast<float*>(smem + STAGE_BYTES + wave_u * EPI_WAVE_BYTES));
+    gemm_epilogue<OutT, MT, MT < 8, ACT>(p, acc, bm_done, bn_done, wr, wc, fr, fh,
+                            reinterpret_cast<float*>(smem + STAGE_BYTES + wave_u * EPI_WAVE_BYTES),
+                            p.nt_mode == 2 || (p.nt_mode == 1 && !more));
 #ifdef SWC_GEMM_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long st_e1 = stamp();
@@ -638,7 +694,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     }
 }
 
-template <int MODE, typename OutT, int MT, int WM, int WN, bool PLAIN, int RB = 128>
+template <int MODE, typename OutT, int MT, int WM, int WN, bool PLAIN, int RB = 128, int ACT = 2>
 int launch_k(GemmP p, hipStream_t s) {
     constexpr int BM = WM * MT * 16, BN = WN * 64;
     constexpr int LDS = 2 * (BM + BN) * RB;
@@ -657,12 +713,20 @@ int launch_k(GemmP p, hipStream_t s) {
         swc_set_error("swc_gemm: grid too large");
         return SWC_E_ARG;
     }
-    auto kern = gemm_kernel<MODE, OutT, MT, WM, WN, PLAIN, RB>;
+    auto kern = gemm_kernel<MODE, OutT, MT, WM, WN, PLAIN, RB, ACT>;
     if (LDS > 64 * 1024) SWC_ENABLE_LDS(kern, LDS, "swc_gemm");
     // persistent grid: one workgroup per CU for the 8-wave geometries, two for the 4-wave one (256 CUs)
     const int persist = tuning_env("SWC_GEMM_NOPERSIST") ? 0 : 1;
     const long slots = 256L * (WM * WN == 4 ? 2 : 1);
     const long grid = (persist && nwg > slots) ? slots : nwg;
+    // Non-temporal epilogue stores: measured per family on MI355X (profiles/r03_gemm_store_policy.txt).  They pay where a
+    // workgroup has ONE tile whose rows leave in whole 256-byte pieces (the f32 slab epilogue) behind a long K loop: the
+    // split-f16 fc2 / out-proj (+12 % / +2 %); with several tiles per workgroup or 16-byte pieces (16-bit outputs) the same
+    // stores cost 15 - 40 %, the bf16 GEMMs gain nothing.
+    {
+        const int forced = tuning_env("SWC_GEMM_NT", -1);
+        p.nt_mode = forced >= 0 ? forced : ((MODE == SWC_F16S && sizeof(OutT) == 4 && MT < 8 && WM * WN == 8 && nwg <= slots) ? 2 : 0);
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), LDS, s, p);
     return SWC_OK;
 }
@@ -673,7 +737,14 @@ int launch(GemmP p, hipStream_t s) {
     const long es = MODE == SWC_BF16 ? 2 : (MODE == SWC_FP8 ? 1 : 4);
     const bool plain = (p.taps == 1) && (p.K % BK == 0) && (p.stride == 1) && (p.pad == 0) && (p.t_in == p.t_out) &&
                        p.lda * es < (1L << 24) && p.ldw * es < (1L << 24);  // 24-bit row pitch: offsets by v_mul_u32_u24
-    return plain ? launch_k<MODE, OutT, MT, WM, WN, true, RB>(p, s) : launch_k<MODE, OutT, MT, WM, WN, false, RB>(p, s);
+    // plain GEMMs with 16- / 8-bit outputs (qkv, fc1 + GELU, pwconv1 + GELU): the activation is compiled in, one epilogue
+    // body per kernel
+    if constexpr (sizeof(OutT) < 4 && MODE != SWC_F32) {
+        if (plain) return p.act == SWC_ACT_GELU ? launch_k<MODE, OutT, MT, WM, WN, true, RB, 1>(p, s) : launch_k<MODE, OutT, MT, WM, WN, true, RB, 0>(p, s);
+        return launch_k<MODE, OutT, MT, WM, WN, false, RB, 2>(p, s);
+    } else {
+        return plain ? launch_k<MODE, OutT, MT, WM, WN, true, RB>(p, s) : launch_k<MODE, OutT, MT, WM, WN, false, RB>(p, s);
+    }
 }
 
 }  // namespace
@@ -691,6 +762,8 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
                       (a->c_dtype == SWC_FP8 && a->a_dtype == SWC_FP8),
                   "swc_gemm: bad c_dtype (FP8 outputs come from FP8 operands only)");
     SWC_CHECK_ARG(a->c_dtype != SWC_F16S || a->a_dtype != SWC_FP8, "swc_gemm: fp8 operands have no split-f16 output");
+    SWC_CHECK_ARG(a->c_dtype != SWC_F16S || a->a_dtype != SWC_BF16, "swc_gemm: bf16 operands have no split-f16 output");
+    SWC_CHECK_ARG(a->c_dtype != SWC_BF16 || a->a_dtype != SWC_F16S, "swc_gemm: split-f16 operands have no bf16 output");
     SWC_CHECK_ARG(a->c_dtype != SWC_F16S || (a->N % 32 == 0 && a->ldc % 32 == 0 && aligned16(a->C)),
                   "swc_gemm: split-f16 output needs N, ldc multiples of 32 (N=%d)", a->N);
     SWC_CHECK_ARG(a->act == SWC_ACT_NONE || a->act == SWC_ACT_GELU, "swc_gemm: bad act");
@@ -726,6 +799,8 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     const int bk = bf ? 64 : (f8 ? 128 : 32);
     p.kc_per_tap = (a->K + bk - 1) / bk;
     p.n_tiles_n = p.n_tiles_m = 0;
+    p.nt_mode = -1;  // chosen per geometry in launch_k (tuning builds: SWC_GEMM_NT forces 0 / 1 / 2)
+    p.stagger = tuning_env("SWC_GEMM_STAGGER", 0);
     p.sat = swc_sat_counter();
     hipStream_t s = (hipStream_t)stream;
     // geometry: the 256x256 / 8-wave tile pays off when its grid still fills the 256 CUs
@@ -738,6 +813,9 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
 #define SWC_LAUNCH(MODE, MT, WM, WN)                                                        \
     (cd == SWC_BF16 ? launch<MODE, bf16_t, MT, WM, WN>(p, s)                                 \
                     : (cd == SWC_F16S ? launch<MODE, f16s_t, MT, WM, WN>(p, s) : launch<MODE, float, MT, WM, WN>(p, s)))
+    // 16-bit outputs come in the operands' own format only (checked above): no split-f16 -> bf16 or bf16 -> split-f16 kernels
+#define SWC_LAUNCH_B(MT, WM, WN) (cd == SWC_BF16 ? launch<SWC_BF16, bf16_t, MT, WM, WN>(p, s) : launch<SWC_BF16, float, MT, WM, WN>(p, s))
+#define SWC_LAUNCH_S(MT, WM, WN) (cd == SWC_F16S ? launch<SWC_F16S, f16s_t, MT, WM, WN>(p, s) : launch<SWC_F16S, float, MT, WM, WN>(p, s))
     // 8-wave geometries differ only in the rows per tile (256 / 192 / 128 x 256 columns): pick the one whose grid
     // quantises best over the 256 CUs.  cost ~ rounds x (rows + fixed per-tile overhead); e.g. M = 16000, N = 768:
     // 189 tiles of 256 rows leave a quarter of the chip idle, 252 tiles of 192 rows fill it in one round.
@@ -769,21 +847,23 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
 #undef SWC_LAUNCH8
     } else if (bf) {
         if (big)
-            rc = mt == 8 ? SWC_LAUNCH(SWC_BF16, 8, 2, 4) : (mt == 6 ? SWC_LAUNCH(SWC_BF16, 6, 2, 4) : SWC_LAUNCH(SWC_BF16, 4, 2, 4));
+            rc = mt == 8 ? SWC_LAUNCH_B(8, 2, 4) : (mt == 6 ? SWC_LAUNCH_B(6, 2, 4) : SWC_LAUNCH_B(4, 2, 4));
         else
-            rc = half_rows ? SWC_LAUNCH(SWC_BF16, 2, 2, 2) : SWC_LAUNCH(SWC_BF16, 4, 2, 2);
+            rc = half_rows ? SWC_LAUNCH_B(2, 2, 2) : SWC_LAUNCH_B(4, 2, 2);
     } else if (fs) {
         bool bigs = a->N >= 256 && big_tiles >= 96;
         if (tile_override() == 128) bigs = false;
         if (tile_override() == 256) bigs = true;
         if (bigs)
-            rc = mt == 8 ? SWC_LAUNCH(SWC_F16S, 8, 2, 4) : (mt == 6 ? SWC_LAUNCH(SWC_F16S, 6, 2, 4) : SWC_LAUNCH(SWC_F16S, 4, 2, 4));
+            rc = mt == 8 ? SWC_LAUNCH_S(8, 2, 4) : (mt == 6 ? SWC_LAUNCH_S(6, 2, 4) : SWC_LAUNCH_S(4, 2, 4));
         else
-            rc = half_rows ? SWC_LAUNCH(SWC_F16S, 2, 2, 2) : SWC_LAUNCH(SWC_F16S, 4, 2, 2);
+            rc = half_rows ? SWC_LAUNCH_S(2, 2, 2) : SWC_LAUNCH_S(4, 2, 2);
     } else {
         rc = SWC_LAUNCH(SWC_F32, 4, 2, 2);
     }
 #undef SWC_LAUNCH
+#undef SWC_LAUNCH_B
+#undef SWC_LAUNCH_S
     if (rc != SWC_OK) return rc;
     SWC_CHECK_LAUNCH("swc_gemm");
     return SWC_OK;

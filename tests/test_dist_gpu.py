@@ -147,12 +147,12 @@ def test_cli_two_ranks_writes_the_single_gpu_files(tmp_path):
         assert (out1 / n).read_bytes() == (out2 / n).read_bytes(), n
 
 
-@pytest.mark.parametrize("n", [2, 5])
+@pytest.mark.parametrize("n", [2, 3])
 def test_bench_multi_rank_rehearsal(n):
     """bench.py --gpus N as the driver launches it (torch.distributed.run, one process per rank), rehearsed on one card:
     SWC_BENCH_BACKEND=gloo carries the traffic through host memory because RCCL refuses two ranks on one GPU.  Checks the
     multi-rank control flow of the bench: one JSON line, from rank 0, covering all ranks' utterances, answer check passed.
-    (5 ranks is what the box allows: at most 6 processes may use its GPU at once; the 8-way layout itself runs in
+    (3 ranks: the box allows at most 6 processes on its GPU at once, the test runner and the launcher included; the 8-way layout runs in
     tests/test_dist_cpu.py.)"""
     import json
     import subprocess
@@ -192,24 +192,41 @@ def _worker_bookkeeping(port, ret):
         dp.world = 8                                   # the helpers below only index per-rank lists with it
         n, B, G = 160000, 256, m.num_groups
         wavs = [torch.zeros(n, device="cuda") for _ in range(B)]
-        times = []
+        times, seg = [], {}
+        got_c = [torch.zeros((32 * G, 125), dtype=torch.int32, device="cuda") for _ in range(8)]  # what the gathers deliver
+        got_w = [torch.zeros((32, n), device="cuda") for _ in range(8)]
+        batch = None
         for it in range(25):
-            got_c = [torch.zeros((32 * G, 125), dtype=torch.int32, device="cuda") for _ in range(8)]  # what the gathers deliver
-            got_w = [torch.zeros((32, n), device="cuda") for _ in range(8)]
+            del batch                                          # (as in a serving loop: last step's batch has been dropped)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            lens = [int(w.shape[-1]) for w in wavs]
+            t0 = t = time.perf_counter()
+
+            def lap(name):
+                nonlocal t
+                now = time.perf_counter()
+                seg.setdefault(name, []).append(now - t)
+                t = now
+            lens = [w.size(-1) for w in wavs]
             parts = partition(lens, dp.world)
             rate, up = m.encoder_downsample_rate, m.decoder_upsample_rate
             clen = [l // rate for l in lens]
             t_max = max(clen)
             cparts = [(pa * G, pb * G) for pa, pb in parts]
+            lap("lengths+partition")
             batch = dp._pad_batch(wavs, lens, torch.float32)      # one gather kernel from an uploaded address list
             shards = [batch[a:b] for a, b in parts]               # what _scatter_rows sends
-            out = {"codes_list": dp._split_codes(got_c, parts, clen), "syn_wav_list": dp._split_wavs(got_w, parts, clen)}
+            lap("batch assembly")
+            codes = dp._split_codes(got_c, parts, clen)
+            lap("code views")
+            out = {"codes_list": codes, "syn_wav_list": dp._split_wavs(got_w, parts, clen)}
+            lap("waveform views")
             times.append(time.perf_counter() - t0)
             assert len(out["codes_list"]) == B and len(out["syn_wav_list"]) == B and len(shards) == 8 and t_max == 125
             assert [b - a for a, b in parts] == [32] * 8 and cparts[1] == (32 * G, 64 * G)
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/parity_report.txt", "a") as f:
+            f.write("dist/rank0_bookkeeping_256 segments_us " + " ".join(
+                f"{k.replace(' ', '_')}={1e6 * sorted(v)[len(v) // 2]:.0f}" for k, v in seg.items()) + "\n")
         times.sort()
         ret.put(times[len(times) // 2])
     finally:
