@@ -245,10 +245,21 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
                 }
             mt = fmaxf(mt, __shfl_xor(mt, 16));
             mt = fmaxf(mt, __shfl_xor(mt, 32));
-            const float m_new = fmaxf(m_run[qt], mt);
-            const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c_exp);
-            m_run[qt] = m_new;
-            const float m_sub = m_new - m_off;
+            // bf16 (decode side): the reference maximum is only moved — and O, l rescaled — when some query column's
+            // maximum has grown by more than 2^8 since it was last fixed (wave-uniform test).  Until then p = 2^((s - m) c)
+            // may exceed 1 by up to 2^8, which bf16 P and the f32 accumulators hold without loss; the normalisation by l
+            // at the end cancels the stale reference exactly.  Saves the 40 multiplies + exp of the rescale on most key
+            // tiles (the kernel is VALU-bound at head_dim 64).  split-f16 (encode side, P carried at scale 2048 in f16,
+            // indices must stay bit-exact) keeps the exact running maximum.
+            bool rescale = true;
+            if constexpr (PLANES == 1) rescale = __builtin_amdgcn_ballot_w64(mt > m_run[qt] + 8.0f / c_exp) != 0;
+            float alpha = 1.0f;
+            if (rescale) {
+                const float m_new = fmaxf(m_run[qt], mt);
+                alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * c_exp);
+                m_run[qt] = m_new;
+            }
+            const float m_sub = m_run[qt] - m_off;
             const float mc = m_sub * c_exp;
             (void)mc;
 #pragma unroll
@@ -259,9 +270,11 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
                     s[qt][ks][e] = PLANES == 1 ? __builtin_amdgcn_exp2f(fmaf(s[qt][ks][e], c_exp, -mc))
                                                : __builtin_amdgcn_exp2f((s[qt][ks][e] - m_sub) * c_exp);
                 }
-            lacc[qt] *= alpha;
+            if (rescale) {
+                lacc[qt] *= alpha;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) o[qt][dt] *= alpha;
+                for (int dt = 0; dt < 4; ++dt) o[qt][dt] *= alpha;
+            }
 #pragma unroll
             for (int pr = 0; pr < NPR; ++pr) {
                 unsigned h[4], lo[4];

@@ -116,6 +116,9 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void epi_st128(void* p, unsigned a, unsigned b, unsigned c, unsigned d, bool nt = false) {
 #if defined(SWC_ABL_NOSTORE)
     asm volatile("" ::"v"(p), "v"(a), "v"(b), "v"(c), "v"(d));
+#elif defined(SWC_EPI_PLAIN)
+    (void)nt;
+    *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
 #else
     if (nt) __builtin_nontemporal_store((u32x4_t){a, b, c, d}, reinterpret_cast<u32x4_t*>(p));
     else *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
@@ -127,6 +130,9 @@ __device__ __forceinline__ void epi_st128f(void* p, float a, float b, float c, f
 __device__ __forceinline__ void epi_st64(void* p, unsigned a, unsigned b, bool nt = false) {
 #if defined(SWC_ABL_NOSTORE)
     asm volatile("" ::"v"(p), "v"(a), "v"(b));
+#elif defined(SWC_EPI_PLAIN)
+    (void)nt;
+    *reinterpret_cast<uint2*>(p) = make_uint2(a, b);
 #else
     if (nt) __builtin_nontemporal_store((u32x2_t){a, b}, reinterpret_cast<u32x2_t*>(p));
     else *reinterpret_cast<uint2*>(p) = make_uint2(a, b);
@@ -135,6 +141,9 @@ __device__ __forceinline__ void epi_st64(void* p, unsigned a, unsigned b, bool n
 __device__ __forceinline__ void epi_st32(void* p, unsigned a, bool nt = false) {
 #if defined(SWC_ABL_NOSTORE)
     asm volatile("" ::"v"(p), "v"(a));
+#elif defined(SWC_EPI_PLAIN)
+    (void)nt;
+    *reinterpret_cast<unsigned*>(p) = a;
 #else
     if (nt) __builtin_nontemporal_store(a, reinterpret_cast<unsigned*>(p));
     else *reinterpret_cast<unsigned*>(p) = a;
@@ -218,25 +227,35 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmP& p, f32x4 (&acc
                         (!p.residual || (p.ldr & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
-    float bv[16], gv[16];
+    // (the multiply by gamma stays in the 16-bit-output bodies although no caller passes one there: compiled out, hipcc gives
+    // the split-f16 fc1 kernel another K-loop schedule that runs 11 % slower — 226 against 204 us per launch, same box,
+    // profiles/r03_gemm_epilogue_ab.txt.  tools/check_isa.py watches the K loop's shape)
+#ifdef SWC_DROP_GAMMA16
+    constexpr bool HAS_GAMMA = sizeof(OutT) == 4;
+#else
+    constexpr bool HAS_GAMMA = true;
+#endif
+    float bv[16], gv[HAS_GAMMA ? 16 : 1];
     float amax = 0.f;
-    (void)amax;
+    (void)amax; (void)gv;
     // a lane's 16 columns are 64 contiguous bytes of bias / gamma: four 16-byte loads when they lie inside N (one load and
     // one branch per column otherwise: 32 dependent-looking scalar loads per tile on the hot GEMMs)
     if (col0 + 16 <= p.N && ((reinterpret_cast<uintptr_t>(p.bias) | reinterpret_cast<uintptr_t>(p.gamma)) & 15) == 0) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 b4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + col0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 g4 = p.gamma ? *reinterpret_cast<const float4*>(p.gamma + col0 + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
             bv[4 * q] = b4.x; bv[4 * q + 1] = b4.y; bv[4 * q + 2] = b4.z; bv[4 * q + 3] = b4.w;
-            gv[4 * q] = g4.x; gv[4 * q + 1] = g4.y; gv[4 * q + 2] = g4.z; gv[4 * q + 3] = g4.w;
+            if constexpr (HAS_GAMMA) {
+                const float4 g4 = p.gamma ? *reinterpret_cast<const float4*>(p.gamma + col0 + 4 * q) : make_float4(1.f, 1.f, 1.f, 1.f);
+                gv[4 * q] = g4.x; gv[4 * q + 1] = g4.y; gv[4 * q + 2] = g4.z; gv[4 * q + 3] = g4.w;
+            }
         }
     } else {
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             const int col = col0 + c;
             bv[c] = (p.bias && col < p.N) ? p.bias[col] : 0.f;
-            gv[c] = (p.gamma && col < p.N) ? p.gamma[col] : 1.f;
+            if constexpr (HAS_GAMMA) gv[c] = (p.gamma && col < p.N) ? p.gamma[col] : 1.f;
         }
     }
 #pragma unroll
@@ -256,8 +275,10 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmP& p, f32x4 (&acc
             for (int c = 0; c < 16; ++c)
                 if (p.act == SWC_ACT_GELU) v[c] = epi_act<OutT>(v[c]);
         }
+        if constexpr (HAS_GAMMA) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] *= gv[c];
+            for (int c = 0; c < 16; ++c) v[c] *= gv[c];
+        }
         if constexpr (sizeof(OutT) == sizeof(f16s_t) && !__is_same(OutT, bf16_t)) {
             // split-f16 output: the lane's 16 columns sit inside one 32-block (col0 % 16 == 0, N % 32 == 0)
             if (col0 + 16 <= p.N) {
@@ -719,14 +740,11 @@ int launch_k(GemmP p, hipStream_t s) {
     const int persist = tuning_env("SWC_GEMM_NOPERSIST") ? 0 : 1;
     const long slots = 256L * (WM * WN == 4 ? 2 : 1);
     const long grid = (persist && nwg > slots) ? slots : nwg;
-    // Non-temporal epilogue stores: measured per family on MI355X (profiles/r03_gemm_store_policy.txt).  They pay where a
-    // workgroup has ONE tile whose rows leave in whole 256-byte pieces (the f32 slab epilogue) behind a long K loop: the
-    // split-f16 fc2 / out-proj (+12 % / +2 %); with several tiles per workgroup or 16-byte pieces (16-bit outputs) the same
-    // stores cost 15 - 40 %, the bf16 GEMMs gain nothing.
-    {
-        const int forced = tuning_env("SWC_GEMM_NT", -1);
-        p.nt_mode = forced >= 0 ? forced : ((MODE == SWC_F16S && sizeof(OutT) == 4 && MT < 8 && WM * WN == 8 && nwg <= slots) ? 2 : 0);
-    }
+    // Non-temporal epilogue stores (profiles/r03_gemm_store_policy.txt): alone on the chip the split-f16 fc2 gains 12 % from
+    // them (one tile per workgroup, whole 256-byte row pieces behind a long K loop), every other shape loses 0 - 40 %; inside
+    // the pipeline the same fc2 / out-proj launches run 1 % SLOWER with them (129 -> 130 us, same-box rocprof A/B): off.
+    // The mode stays selectable in tuning builds.
+    p.nt_mode = tuning_env("SWC_GEMM_NT", 0);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WM * WN * 64), LDS, s, p);
     return SWC_OK;
 }

@@ -515,6 +515,32 @@ def test_attention16_spike():
     assert (out - ref).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("spike_keys", [[], [150], [70, 130, 390], [5]])
+def test_attention16_bf16_lazy_rescale(spike_keys):
+    """bf16 kernel: the softmax reference maximum moves only when a query column's maximum has grown by more than 2^8
+    (swc_attention16.hip).  Full-tensor check against float64 with inputs that (a) never trigger a rescale after the first
+    key tile ([]: scores stay within 2^8 of the first tile's maximum), (b) force it in a late tile by a spiked key, (c) in
+    several tiles with growing spikes, (d) only in the first tile — and rows whose own maximum did NOT grow ride along
+    with a stale reference (the test compares every query)."""
+    ops = _ops()
+    B, T, H = 2, 470, 2
+    g = torch.Generator().manual_seed(11 + len(spike_keys))
+    qkv = torch.randn(B, T, 3 * H * 64, generator=g) * 0.35
+    for n, key in enumerate(spike_keys):      # key `key` of head 0 lines up with query 10 (and partly with others): a score spike
+        qkv[0, key, H * 64:H * 64 + 64] = qkv[0, 10, 0:64] * (25.0 + 20.0 * n)
+        qkv[1, key, H * 64 + 64:H * 64 + 128] = qkv[1, 300, 64:128] * (25.0 + 20.0 * n)
+    qd = qkv.to(torch.bfloat16)
+    lens = [T, 333]
+    out = ops.attention(qd.to(DEV), torch.tensor(lens, dtype=torch.int32, device=DEV), B, T, H).float().cpu().double()
+    assert torch.isfinite(out).all()
+    q, k, v = [t.reshape(B, T, H, 64).transpose(1, 2).double() for t in qd.float().chunk(3, dim=-1)]
+    for b, L in enumerate(lens):
+        s_ = q[b, :, :L] @ k[b, :, :L].transpose(-1, -2)
+        ref = (torch.softmax(s_, -1) @ v[b, :, :L]).transpose(0, 1).reshape(L, H * 64)
+        err = (out[b, :L] - ref).abs().max().item()
+        assert err < 1.5e-2, (b, spike_keys, err)
+
+
 def test_code_bitstream(tmp_path):
     from simwhisper_codec_amd import bitstream
     from oracle import bitstream_np
