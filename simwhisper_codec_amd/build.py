@@ -16,7 +16,13 @@ SOURCES = ["swc_api.hip", "swc_gemm.hip", "swc_attention.hip", "swc_attention16.
 ARCH = "gfx950"
 # per-file flags.  -fno-slp-vectorize: hipcc otherwise packs adjacent f32 mul/add/fma into v_pk_*_f32, which issue at
 # half rate on gfx950 and cost extra v_mov shuffles — slower beside MFMAs (softmax, epilogues)
-EXTRA_FLAGS = {"swc_attention16.hip": ["-fno-slp-vectorize"], "swc_convnext.hip": ["-fno-slp-vectorize"]}  # measured slower for swc_gemm.hip (-10 %)
+# -mllvm -amdgpu-sched-strategy=max-ilp: LLVM's max-ILP machine scheduler instead of the default (occupancy-driven) one for
+# the two MFMA-loop files: same instructions, another order (results bit-identical); same-box A/B of the whole step
+# 22.19 -> 21.90 ms (swc_gemm.hip) -> 21.80 ms (+ swc_convnext.hip), split-f16 GEMMs -2.5 ... -3.4 %, ConvNeXt block 254.8 ->
+# 249.9 us; swc_attention16.hip gets slower with it (99.9 -> 102.9 us) and keeps the default (profiles/r03_sched_strategy_ab.txt)
+_MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+EXTRA_FLAGS = {"swc_attention16.hip": ["-fno-slp-vectorize"], "swc_convnext.hip": ["-fno-slp-vectorize"] + _MAX_ILP,
+               "swc_gemm.hip": _MAX_ILP}  # (-fno-slp-vectorize measured slower for swc_gemm.hip: -10 %)
 
 
 def _hipcc():

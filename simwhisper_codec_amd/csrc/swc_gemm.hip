@@ -511,11 +511,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     auto stage_slice = [&](int kt, int stage) {
         const unsigned sa = smem_base + stage * STAGE_BYTES + wave_u * 1024;  // one wave-instruction = 1 KiB of rows
         const unsigned sb = sa + A_BYTES;
-        // Never taken (kc_per_tap >= 1).  The uniform branch makes the LDS-DMA issue block its own scheduling region:
-        // without it hipcc interleaves the fragment reads of the current slice differently with the first MFMAs and
-        // the whole step runs 6.5 % slower (same-box A/B, profiles/r02_ab_sched_region.txt; a sched_barrier(0) in its
-        // place gives a third, also slower, order).
-        if (p.kc_per_tap <= 0) return;
+        // (round 2 kept a never-taken uniform branch here: under hipcc's default scheduler it made the DMA block its own
+        // scheduling region and was worth 6.5 % of the step.  With -amdgpu-sched-strategy=max-ilp (build.py) the K loop has the
+        // same shape with and without it — tools/check_isa.py, profiles/r03_sched_strategy_ab.txt — and it is gone.)
         if constexpr (PLAIN) {
             const long koff = (long)kt * ROW_BYTES;
             const char* ab = a_base + koff;
@@ -591,10 +589,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
     const int b_row0 = wc * 64 + 16 * (fr >> 2) + (fr & 3);
     stage_slice(0, 0);
     dma_fence();
+#ifdef SWC_GEMM_PRIO47   // tuning experiment: static priority for the second wave of every SIMD (MI355X_MICROARCH.md item 4)
+    if (wave_u >= (WAVES_M * WAVES_N) / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     for (;;) {
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nkt) stage_slice(kt + 1, cur ^ 1);
+#ifdef SWC_GEMM_IGLP     // tuning experiment: LLVM's MFMA / DS interleaving pipelines for this scheduling region
+        __builtin_amdgcn_iglp_opt(SWC_GEMM_IGLP);
+#endif
         const char* sa = smem + cur * STAGE_BYTES;
         const char* sb = sa + A_BYTES;
         uint4 ha[(F16S || FP8) ? MT : 1], hb[(F16S || FP8) ? 4 : 1];  // first 16-byte chunk of a fragment, kept until the second is read
