@@ -111,7 +111,7 @@ typedef struct swc_gemm_args {
     const void* W;
     void* C;
     const float* bias;     /* [N] or NULL */
-    const float* gamma;    /* [N] or NULL */
+    const float* gamma;    /* [N] or NULL; f32 outputs only (c_dtype == SWC_F32) */
     const float* residual; /* [M][ldr] f32 or NULL (may alias C when c_dtype == F32) */
     int64_t lda, ldw, ldc, ldr;
     int32_t M, N, K;

@@ -227,13 +227,15 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmP& p, f32x4 (&acc
                         (!p.residual || (p.ldr & 3) == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                         ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0);
-    // (the multiply by gamma stays in the 16-bit-output bodies although no caller passes one there: compiled out, hipcc gives
-    // the split-f16 fc1 kernel another K-loop schedule that runs 11 % slower — 226 against 204 us per launch, same box,
-    // profiles/r03_gemm_epilogue_ab.txt.  tools/check_isa.py watches the K loop's shape)
-#ifdef SWC_DROP_GAMMA16
-    constexpr bool HAS_GAMMA = sizeof(OutT) == 4;
-#else
+    // gamma (ConvNeXt layer scale) exists for f32 outputs only (swc_gemm checks): the 16-bit-output bodies do not carry a
+    // multiply by 1.0 per output (bf16 fc1 / qkv -3 %, profiles/r03_gemm_split_ab.txt).  History: under hipcc's default
+    // scheduler compiling it out flipped the split-f16 fc1 kernel into a K-loop schedule that ran 11 % slower (226 against
+    // 204 us, profiles/r03_gemm_epilogue_ab.txt); with the max-ilp scheduler and the explicit fence split the K loop no longer
+    // depends on the epilogue (tools/check_isa.py watches its shape)
+#ifdef SWC_KEEP_GAMMA16
     constexpr bool HAS_GAMMA = true;
+#else
+    constexpr bool HAS_GAMMA = sizeof(OutT) == 4;
 #endif
     float bv[16], gv[HAS_GAMMA ? 16 : 1];
     float amax = 0.f;
@@ -601,6 +603,58 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
 #endif
         const char* sa = smem + cur * STAGE_BYTES;
         const char* sb = sa + A_BYTES;
+        // 8-wave bf16 / split-f16 geometries: the slice's fragments go to registers first, and the MFMAs of the LAST `SPLIT` row
+        // blocks are issued BEHIND the slice fence: they need registers only, so they fill the matrix pipe while the waves
+        // come out of the barrier, issue the next slice's LDS-DMA and wait for its first fragment reads.  hipcc moves MFMAs
+        // across a barrier at will (they touch no memory) and its choice changed with unrelated edits (25 ... 59 of 96 behind,
+        // 204 ... 226 us per launch of the same GEMM); here the split is explicit and pinned by scheduling barriers.  Measured
+        // per kernel, same box, us per launch with 0 / 1 / 2 / 3 row blocks behind the fence (profiles/r03_gemm_split_ab.txt):
+        //   split-f16 256-row (fc1)  223.0 / 209.0 / 205.1 / 202.1     192-row f32-out 134.2 / 124.0 / 127.6 / 129.5, qkv 160.4 / 151.3 / 152.4 / 152.8
+        //   bf16      256-row (fc1)   97.6 /  95.8 /  95.5 /  95.3     192-row f32-out  64.3 /  64.3 /  66.4 /  67.8, qkv  74.0 /  73.5 /  73.3 /  74.4
+        // Same products in the same order per accumulator: results bit-identical to the plain loop below.
+        // The bf16 kernels keep the compiler's own placement (3 - 5 MFMAs behind the fence under max-ilp): none of the explicit
+        // splits beat it there.
+#ifdef SWC_GEMM_SPLIT
+        constexpr bool EXPLICIT_SPLIT = (BF16 || F16S) && WAVES_M * WAVES_N == 8 && MT >= 4;
+        constexpr int SPLIT = SWC_GEMM_SPLIT;
+#else
+        constexpr bool EXPLICIT_SPLIT = F16S && WAVES_M * WAVES_N == 8 && MT >= 4;
+        constexpr int SPLIT = MT == 8 ? 3 : 1;
+#endif
+        if constexpr (EXPLICIT_SPLIT) {
+            uint4 f0a[MT], f0b[4], f1a[MT], f1b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f0b[j] = *reinterpret_cast<const uint4*>(sb + lds_off<RB>(b_row0 + 4 * j, fh));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) f0a[i] = *reinterpret_cast<const uint4*>(sa + lds_off<RB>(a_row0 + 16 * i, fh));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) f1b[j] = *reinterpret_cast<const uint4*>(sb + lds_off<RB>(b_row0 + 4 * j, fh + 4));
+#pragma unroll
+            for (int i = 0; i < MT; ++i) f1a[i] = *reinterpret_cast<const uint4*>(sa + lds_off<RB>(a_row0 + 16 * i, fh + 4));
+            auto mm = [&](int i) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 c = acc[i][j];
+                    if constexpr (F16S) {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&f1b[j]), *reinterpret_cast<f16x8*>(&f0a[i]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&f0b[j]), *reinterpret_cast<f16x8*>(&f1a[i]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<f16x8*>(&f0b[j]), *reinterpret_cast<f16x8*>(&f0a[i]), c, 0, 0, 0);
+                    } else {
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&f0b[j]), *reinterpret_cast<bf16x8*>(&f0a[i]), c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&f1b[j]), *reinterpret_cast<bf16x8*>(&f1a[i]), c, 0, 0, 0);
+                    }
+                    acc[i][j] = c;
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < MT - SPLIT; ++i) mm(i);
+            __builtin_amdgcn_sched_barrier(0);  // MFMAs touch no memory: without these hipcc moves them across the fence at will
+            dma_fence();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = MT - SPLIT; i < MT; ++i) mm(i);
+            continue;
+        }
         uint4 ha[(F16S || FP8) ? MT : 1], hb[(F16S || FP8) ? 4 : 1];  // first 16-byte chunk of a fragment, kept until the second is read
         (void)ha; (void)hb;
 #pragma unroll
@@ -789,6 +843,7 @@ extern "C" int swc_gemm(const swc_gemm_args* a, void* stream) {
     SWC_CHECK_ARG(a->c_dtype != SWC_F16S || (a->N % 32 == 0 && a->ldc % 32 == 0 && aligned16(a->C)),
                   "swc_gemm: split-f16 output needs N, ldc multiples of 32 (N=%d)", a->N);
     SWC_CHECK_ARG(a->act == SWC_ACT_NONE || a->act == SWC_ACT_GELU, "swc_gemm: bad act");
+    SWC_CHECK_ARG(!a->gamma || a->c_dtype == SWC_F32, "swc_gemm: gamma (per-column output scale) exists for f32 outputs only");
     const bool bf = a->a_dtype == SWC_BF16;
     const bool fs = a->a_dtype == SWC_F16S;
     const bool f8 = a->a_dtype == SWC_FP8;

@@ -32,9 +32,10 @@ MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 #   MODE 1 bf16 (BK 64: MT*4 tiles x 2 k-groups), MODE 2 split-f16 (BK 32: MT*4 tiles x 3 products)
 EXPECT = {
     # name fragment                                  mfma  ds_read  dma   what it is
-    "gemm_kernelILi2E6f16s_tLi8ELi2ELi4ELb1ELi128ELi1E": (96, 24, 8, "split-f16 fc1 + GELU (256 x 256)"),
-    "gemm_kernelILi2E6f16s_tLi6ELi2ELi4ELb1ELi128ELi0E": (72, 20, 7, "split-f16 qkv (192 x 256)"),
-    "gemm_kernelILi2EfLi6ELi2ELi4ELb1ELi128ELi2E": (72, 20, 7, "split-f16 out-proj / fc2 (192 x 256, f32 out)"),
+    # (split-f16: the number of MFMAs behind the slice fence is set in the source — 3 row blocks of 12 at 256 rows, 1 at 192)
+    "gemm_kernelILi2E6f16s_tLi8ELi2ELi4ELb1ELi128ELi1E": (96, 24, 8, "split-f16 fc1 + GELU (256 x 256)", 36),
+    "gemm_kernelILi2E6f16s_tLi6ELi2ELi4ELb1ELi128ELi0E": (72, 20, 7, "split-f16 qkv (192 x 256)", 12),
+    "gemm_kernelILi2EfLi6ELi2ELi4ELb1ELi128ELi2E": (72, 20, 7, "split-f16 out-proj / fc2 (192 x 256, f32 out)", 12),
     "gemm_kernelILi1EtLi8ELi2ELi4ELb1ELi128ELi1E": (64, 24, 8, "bf16 fc1 / pwconv1 + GELU (256 x 256)"),
     "gemm_kernelILi1EtLi6ELi2ELi4ELb1ELi128ELi0E": (48, 20, 7, "bf16 qkv (192 x 256)"),
     "gemm_kernelILi1EfLi6ELi2ELi4ELb1ELi128ELi2E": (48, 20, 7, "bf16 out-proj / fc2 / heads (192 x 256, f32 out)"),
@@ -95,7 +96,9 @@ def check(path):
         if frag not in found:
             bad.append(f"{exp[3]}: kernel {frag} not found in {path}")
             continue
-        name, body, (n_mfma, n_read, n_dma, what) = found[frag]
+        name, body, exp = found[frag]
+        n_mfma, n_read, n_dma, what = exp[:4]
+        n_behind = exp[4] if len(exp) > 4 else None
         body = [ln for ln in body if re.search(r"//\s*[0-9A-Fa-f]+:", ln)]  # instructions only (no labels / padding notes)
         text = [re.sub(r"\s*//.*$", "", ln) for ln in body]
         if any(t.startswith("scratch_") for t in text):
@@ -149,6 +152,8 @@ def check(path):
         if vm0 != 1:
             msgs.append(f"{vm0} `s_waitcnt vmcnt(0)` per slice, expected 1")
         behind = sum(t.startswith("v_mfma") for t in loop[bar:])
+        if n_behind is not None and behind != n_behind:
+            msgs.append(f"{behind} MFMAs behind the slice fence, the source asks for {n_behind}")
         if 2 * behind > nm:   # the slow schedule of r03 (fc1 226 us instead of 204) had 59 of 96 behind the barrier and two waits
             msgs.append(f"{behind} of {nm} MFMAs sit behind the slice barrier (more than half: the schedule that measured 11 % slower)")
         for m_ in msgs:
