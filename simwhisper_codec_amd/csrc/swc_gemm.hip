@@ -177,17 +177,31 @@ __device__ __forceinline__ void gemm_epilogue_slab(const GemmP& p, f32x4 (&acc)[
     if (p.gamma) g4 = *reinterpret_cast<const float4*>(p.gamma + col);
     float* wr_p = tbuf + (lane & 15) * EPI_TP + (lane >> 4) * 16;
     const float* rd_p = tbuf + tr * EPI_TP + tc;
+    // The residual rows of block i + RD are requested before block i is processed (a rolling window of RD + 1 blocks in
+    // registers).  C may alias the residual (the residual stream is updated in place), so hipcc keeps every load behind the
+    // stores that precede it in program order: loaded block by block, each of the MT blocks waited a full memory latency with
+    // every CU doing the same (26 - 33 k cycles per 192 x 256 tile, in-kernel stamps).  All MT blocks at once (16 MT
+    // registers) made the K loop spill; RD blocks ahead cost 16 RD registers that are free in the epilogue.
+#ifndef SWC_EPI_RD
+#define SWC_EPI_RD 2
+#endif
+    constexpr int RD = SWC_EPI_RD < MT ? SWC_EPI_RD : MT - 1;
+    float4 r4[MT][4];
+    auto load_res = [&](int i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = row0 + 16 * i + tr + 4 * k;
+            r4[i][k] = row < p.M ? *reinterpret_cast<const float4*>(p.residual + (long)row * p.ldr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    if (p.residual) {
+#pragma unroll
+        for (int i = 0; i < RD; ++i) load_res(i);
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         const int rbase = row0 + 16 * i + tr;
-        float4 r4[4];
-        if (p.residual) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int row = rbase + 4 * k;
-                r4[k] = row < p.M ? *reinterpret_cast<const float4*>(p.residual + (long)row * p.ldr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+        if (p.residual && i + RD < MT) load_res(i + RD);
 #pragma unroll
         for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(wr_p + 4 * j) = acc[i][j];
         f32x4 t[4];
@@ -199,7 +213,7 @@ __device__ __forceinline__ void gemm_epilogue_slab(const GemmP& p, f32x4 (&acc)[
             float v0 = t[k][0] * p.alpha + b4.x, v1 = t[k][1] * p.alpha + b4.y, v2 = t[k][2] * p.alpha + b4.z, v3 = t[k][3] * p.alpha + b4.w;
             if constexpr (GELU) { v0 = epi_act<OutT>(v0); v1 = epi_act<OutT>(v1); v2 = epi_act<OutT>(v2); v3 = epi_act<OutT>(v3); }
             v0 *= g4.x; v1 *= g4.y; v2 *= g4.z; v3 *= g4.w;
-            if (p.residual) { v0 += r4[k].x; v1 += r4[k].y; v2 += r4[k].z; v3 += r4[k].w; }
+            if (p.residual) { v0 += r4[i][k].x; v1 += r4[i][k].y; v2 += r4[i][k].z; v3 += r4[i][k].w; }
             if (row >= p.M) continue;
             if constexpr (__is_same(OutT, f16s_t)) {
                 const float os = p.out_scale;
