@@ -26,7 +26,8 @@ Rank 0 prints ONE JSON line, with
                  box's host cores on a bounded sample of the same workload (N = 1 only): B = 8 x 10 s (BASELINE.json
                  configs[1]'s shape, the first 8 draws of the same generator), 1 warm-up + 3 timed passes, median (~60 s).
   parity       — the run checks its own answer: the codes of utterance 0 of the LAST timed step must equal the CPU oracle's
-                 bit for bit and its waveform must lie within the bf16-decode tolerance of the oracle's (N = 1, cpu baseline
+                 (at most 2 of 1000 may differ — the oracle's own thread-count sensitivity; the count is reported and has been 0
+                 on every box) and its waveform must lie within the bf16-decode tolerance of the oracle's (N = 1, cpu baseline
                  on: the oracle's warm-up pass supplies them); otherwise utterance 0 encoded alone on the GPU (rows of a
                  batch are independent).  A wrong answer fails the bench.
   other_configs — after the metric measurements (N = 1): the other BASELINE.json configs, a few steps each, every one with
@@ -311,7 +312,11 @@ def main():
             assert got.shape == want.shape, (got.shape, want.shape)
             d = int((got != want).sum())
             if i == 0 and exact_codes:
-                assert d == 0, f"bench: {d} of {want.numel()} codes of utterance 0 differ from {expect['source']}"
+                # the CPU oracle's own codes move with its host thread count (2 of 94 544 between 1 and 16 threads,
+                # profiles/r02_code_agreement.txt: a latent within 1e-6 of a rounding boundary): the bench must not fail on
+                # that, a wrong kernel flips hundreds.  The exact count is on the line (`parity.code_mismatches`, 0 on every box
+                # so far); the bit-exact bar itself is held by tests/test_metric_shape_gpu.py and tests/test_parity_gpu.py
+                assert d <= 2, f"bench: {d} of {want.numel()} codes of utterance 0 differ from {expect['source']}"
             mism += d; total += want.numel()
         if exact_codes:  # waveform given the SAME codes; presets with a statistical encoder differ in codes
             for i, want in enumerate(expect["wav"]):
