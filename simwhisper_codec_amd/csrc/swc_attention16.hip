@@ -32,6 +32,15 @@ __device__ __forceinline__ void glds16a(const void* gsrc, unsigned lds_addr) {
         : "memory");
 }
 
+// max over the lane pair (l, l ^ W), W = 16 or 32, in both lanes: operand rows swapped against a copy of themselves
+typedef unsigned u32x2_sw __attribute__((ext_vector_type(2)));
+template <int W>
+__device__ __forceinline__ float xor_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const u32x2_sw r = W == 16 ? __builtin_amdgcn_permlane16_swap(u, u, false, false) : __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 template <int PLANES>
 __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 c) {
     if constexpr (PLANES == 1)
@@ -243,8 +252,18 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
                     s[qt][ks][e] = v;
                     mt = fmaxf(mt, v);
                 }
-            mt = fmaxf(mt, __shfl_xor(mt, 16));
-            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            // the four lane groups (fh) of a query column hold partial maxima: combined with the gfx950 row swaps
+            // (v_permlane16_swap / v_permlane32_swap: plain vector instructions) — __shfl_xor compiles to ds_bpermute_b32,
+            // a round trip through the LDS crossbar, twice in the dependent chain max -> exp of every key tile
+            // (bf16 kernel: 47.5 -> 46.2 us per launch in the pipeline; the split-f16 kernel gets another register
+            // allocation with them and runs 3.6 % slower, 103.3 -> 107.0 us: it keeps the shuffles)
+            if constexpr (PLANES == 1) {
+                mt = xor_max<16>(mt);
+                mt = xor_max<32>(mt);
+            } else {
+                mt = fmaxf(mt, __shfl_xor(mt, 16));
+                mt = fmaxf(mt, __shfl_xor(mt, 32));
+            }
             // bf16 (decode side): the reference maximum is only moved — and O, l rescaled — when some query column's
             // maximum has grown by more than 2^8 since it was last fixed (wave-uniform test).  Until then p = 2^((s - m) c)
             // may exceed 1 by up to 2^8, which bf16 P and the f32 accumulators hold without loss; the normalisation by l
