@@ -632,8 +632,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_kernel(GemmP p)
         constexpr bool EXPLICIT_SPLIT = (BF16 || F16S) && WAVES_M * WAVES_N == 8 && MT >= 4;
         constexpr int SPLIT = SWC_GEMM_SPLIT;
 #else
-        constexpr bool EXPLICIT_SPLIT = F16S && WAVES_M * WAVES_N == 8 && MT >= 4;
-        constexpr int SPLIT = MT == 8 ? 3 : 1;
+        // The 4-wave geometries (two workgroups per CU, out of phase by themselves; the GEMMs of small batches) take the
+        // same body with NOTHING behind the fence: B = 8 x 10 s `mixed` 9.46 -> 9.22 ms per step, `bf16` 7.38 -> 7.34; one
+        // row block behind it is slower (9.50 / 7.47).
+        constexpr bool EXPLICIT_SPLIT = (F16S && WAVES_M * WAVES_N == 8 && MT >= 4) || ((BF16 || F16S) && WAVES_M * WAVES_N == 4);
+        constexpr int SPLIT = WAVES_M * WAVES_N == 4 ? 0 : (MT == 8 ? 3 : 1);
 #endif
         if constexpr (EXPLICIT_SPLIT) {
             uint4 f0a[MT], f0b[4], f1a[MT], f1b[4];
