@@ -395,7 +395,7 @@ class AudioCodec(nn.Module):
 
     # encode-side operand fields of _Packed that depend on the encode operand type: what a packed-operand file stores a
     # second time, in exact f32, for the range-guard fallback (mixed -> mixed_f32)
-    _ENCODE_FIELDS = ("edt", "c1dt", "c1w", "c1b", "c2w", "c2b", "enc_ldt", "enc_layers", "enc_ln", "inw", "inb",
+    _ENCODE_FIELDS = ("edt", "c1dt", "c1k", "c1w", "c1b", "c2w", "c2b", "enc_ldt", "enc_layers", "enc_ln", "inw", "inb",
                       "down_units", "tlw", "tlb")
     _FALLBACK_OF = {"mixed": "mixed_f32"}
 
@@ -423,6 +423,8 @@ class AudioCodec(nn.Module):
         if meta["abi"] != ops.abi_version():
             raise SwcError(f"{self._packed_file}: packed for library ABI {meta['abi']}, this is {ops.abi_version()}: "
                            "pack the checkpoint again")
+        if not hasattr(P, "c1k"):   # a file written before conv1 had a padded form: n_mel bins per tap, as packed
+            P.c1k = P.n_mel
         if meta["precision"] == self._precision:
             return P
         if self._FALLBACK_OF.get(meta["precision"]) == self._precision:
@@ -432,7 +434,7 @@ class AudioCodec(nn.Module):
                                f"(written by an older tools/pack_checkpoint.py): pack the checkpoint again, pack it for "
                                f"precision={self._precision!r}, or load the .pt")
             for k in self._ENCODE_FIELDS:
-                setattr(P, k, fb[k])
+                setattr(P, k, fb[k] if k != "c1k" else fb.get(k, P.n_mel))
             return P
         raise SwcError(f"{self._packed_file}: packed for precision {meta['precision']}, this is {self._precision}: "
                        "pack the checkpoint again")
@@ -548,10 +550,21 @@ class AudioCodec(nn.Module):
         P.dft = _PW(V(spec.dft_basis_400()))                               # [402][400] f32 always
         fb = torch.from_numpy(spec.slaney_mel_filters(n_mels=P.n_mel)).float().T.contiguous()  # [80][201]
         P.melw = _PW(V(torch.nn.functional.pad(fb, (0, 208 - 201))))      # [80][208]
-        # conv1 contracts K = 80 mel bins per tap: not a multiple of 32, so split-f16 keeps it on the exact-f32 path
+        # conv1 contracts K = 80 mel bins per tap: not a multiple of the 32-element split-f16 block.  The log-mel stays f32
+        # (P.c1dt: what _logmel returns and forward() is given); for the split-f16 preset _encoder_impl zero-pads the bins to
+        # 96 and converts, and the weights are packed [D][3][96]: conv1 then runs on the split-f16 MFMA path like every other
+        # encoder GEMM (151 -> ~55 us per step at 32 x 10 s; it was the last exact-f32 GEMM of the `mixed` encode side)
         c1dt = torch.float32 if edt == torch.float16 else edt
         P.c1dt = c1dt
-        P.c1w, P.c1b = W(conv_w(sd["acoustic_encoder.conv1.weight"]), c1dt), V(sd["acoustic_encoder.conv1.bias"])
+        P.c1k = P.n_mel
+        w1c = sd["acoustic_encoder.conv1.weight"]                       # (D, n_mel, 3)
+        if edt == torch.float16 and self.conv1_split_f16:
+            P.c1k = spec.cdiv(P.n_mel, 32) * 32
+            w1c = torch.nn.functional.pad(w1c, (0, 0, 0, P.c1k - P.n_mel))
+            P.c1w = W(conv_w(w1c), torch.float16)
+        else:
+            P.c1w = W(conv_w(w1c), c1dt)
+        P.c1b = V(sd["acoustic_encoder.conv1.bias"])
         P.c2w, P.c2b = W(conv_w(sd["acoustic_encoder.conv2.weight"]), edt), V(sd["acoustic_encoder.conv2.bias"])
         P.enc_ldt = ops.FP8_T if self._precision == "fp8" else edt  # operand type of the encoder-transformer linears
         P.enc_layers = layers("acoustic_encoder", e["encoder_layers"], P.enc_ldt)
@@ -655,6 +668,7 @@ class AudioCodec(nn.Module):
             self._mm(f, L.w2, M, D, F_, lda=F_, bias=L.b2, residual=h, out=h)
         return h
 
+    conv1_split_f16 = True  # `mixed`: conv1 on the split-f16 MFMA path (mel bins padded 80 -> 96); False: exact f32 (read at pack time)
     varlen_packing = True   # ragged calls: the transformers run on the valid tokens only (packed rows), not on B x longest
     PACK_BELOW = 0.9        # ... when the valid tokens are under this fraction of the padded rows
 
@@ -699,7 +713,8 @@ class AudioCodec(nn.Module):
         mp = self._mm(pw, P.melw, M, P.n_mel, 208, lda=208)
         umax = torch.full((B,), -10.0 if Tm < spec.MEL_FRAMES else float("-inf"), device=wav.device, dtype=torch.float32)
         ops.mel_logmax(mp, P.n_mel, umax, B=B, T=Tm, n_mel=P.n_mel)
-        mel = ops.mel_final(mp, P.n_mel, umax, B=B, T=Tm, n_mel=P.n_mel, ldo=P.n_mel, out_dtype=P.c1dt)
+        # (ldo = P.c1k: the split-f16 conv1 reads 96 bins per frame; swc_mel_final zeroes the columns beyond n_mel)
+        mel = ops.mel_final(mp, P.n_mel, umax, B=B, T=Tm, n_mel=P.n_mel, ldo=P.c1k, out_dtype=P.c1dt)
         return mel, Tm
 
     def _encoder(self, mel, Tm, t_full, tok_host, P):
@@ -714,7 +729,12 @@ class AudioCodec(nn.Module):
         B, dt, D = mel.shape[0], P.edt, P.D
         dev = mel.device
         Ttok = max(1, min(t_full, max(tok_host)))
-        c1 = self._mm(mel, P.c1w, B * Tm, D, P.n_mel, lda=P.n_mel, ldw=3 * P.n_mel, bias=P.c1b, taps=3, pad=1, t_in=Tm,
+        K1 = P.c1k
+        if K1 != P.n_mel:  # split-f16 conv1: bins zero-padded to a multiple of 32 (by _logmel already), one conversion pass
+            if mel.shape[-1] != K1:   # a caller's own [B, T, n_mel] mel (forward(), stage tests)
+                mel = torch.nn.functional.pad(mel.to(torch.float32), (0, K1 - mel.shape[-1]))
+            mel = ops.cast_f16s(mel.view(B * Tm, K1), K1)
+        c1 = self._mm(mel, P.c1w, B * Tm, D, K1, lda=K1, ldw=3 * K1, bias=P.c1b, taps=3, pad=1, t_in=Tm,
                       t_out=Tm, out_dtype=dt)
         h = self._mm(c1, P.c2w, B * Ttok, D, D, lda=D, ldw=3 * D, bias=P.c2b, taps=3, stride=2, pad=1, t_in=Tm, t_out=Ttok)
         tok_c = [min(t, Ttok) for t in tok_host]
