@@ -43,6 +43,10 @@ __device__ __forceinline__ float xor_max(float v) {
 
 template <int PLANES>
 __device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 c) {
+#if defined(ATT_ABL) && (ATT_ABL & 8)   // timing ablation only (wrong results): no matrix instruction, operands kept alive
+    c[0] += __uint_as_float(a.x ^ b.x);
+    return c;
+#endif
     if constexpr (PLANES == 1)
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a),
                                                        *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
@@ -205,7 +209,9 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
     auto tile = [&](int kt, auto last_c) {
         constexpr bool LAST = decltype(last_c)::value;
         const int st = kt & 1;
+#if !(defined(ATT_ABL) && (ATT_ABL & 32))   // timing ablation only (wrong results): the next tile is not staged
         if (!LAST) stage(kt + 1, st ^ 1);
+#endif
         const char* sK = smem + st * 2 * TILE;
         const char* sV = sK + TILE;
         const int k0 = kt * KT16;
@@ -221,7 +227,11 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
 #pragma unroll
                 for (int pl = 0; pl < PLANES; ++pl) {
                     const int c = PLANES == 1 ? (4 * g + fh) : (8 * g + 4 * pl + fh);
+#if defined(ATT_ABL) && (ATT_ABL & 16)   // timing ablation only (wrong results): no LDS fragment reads
+                    kf[g][pl] = qf[0][g][pl];
+#else
                     kf[g][pl] = *reinterpret_cast<const uint4*>(sK + row * ROWB + ((c ^ krow_swz(row)) << 4));
+#endif
                 }
 #pragma unroll
             for (int qt = 0; qt < NQT; ++qt) {
@@ -239,6 +249,15 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
         }
         // mask, online softmax per query tile, P fragments
         uint4 pf[NQT][NPR][PLANES];  // [qt][pair][plane]
+#if defined(ATT_ABL) && (ATT_ABL & 4)   // timing ablation only (wrong results): no softmax arithmetic, P = raw score bits
+#pragma unroll
+        for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+            for (int pr = 0; pr < NPR; ++pr)
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl)
+                    pf[qt][pr][pl] = *reinterpret_cast<uint4*>(&s[qt][(2 * pr + pl) % NKS]);
+#else
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt) {
             float mt = -INFINITY;
@@ -314,6 +333,7 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
                 if constexpr (PLANES == 2) pf[qt][pr][1] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
             }
         }
+#endif
         // O^T[d][q] += V^T[d][key] P^T[key][q]
         const int tq = fr >> 2, tp = fr & 3;  // transposing read: this lane addresses row tq, columns 4 tp .. 4 tp + 3
 #pragma unroll
@@ -334,6 +354,9 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
                     }
                     s16x8 full = __builtin_shufflevector(part2[0], part2[1], 0, 1, 2, 3, 4, 5, 6, 7);
                     vf[pl] = *reinterpret_cast<uint4*>(&full);
+#if defined(ATT_ABL) && (ATT_ABL & 16)
+                    vf[pl] = qf[0][pl & 1][0];
+#endif
                 }
 #pragma unroll
                 for (int qt = 0; qt < NQT; ++qt) {
