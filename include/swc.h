@@ -300,6 +300,18 @@ int swc_cast_fp8(const void* x, int32_t x_dtype, void* y, int64_t n, float scale
 int swc_gather_rows(const void* const* src, const int64_t* nbytes, void* out, int64_t ld_bytes, int32_t n_rows,
                     void* stream);
 
+/*
+ * PCM16 <-> f32 on the device (the file loop around the path; utils/helpers.py:77-104 leaves both to
+ * torchaudio.load / torchaudio.save on the host).  Files cross PCIe as 16-bit samples, half the bytes of f32, and the host
+ * threads of inference.py only read and write bytes.
+ *   pcm16_to_f32: out[i] = pcm[i] * 2^-15                          (torchaudio.load's normalisation; exact)
+ *   f32_to_pcm16: pcm[i] = round_half_even(clip(x[i], -1, 1) * 32767), every step in f32 — the values
+ *                 simwhisper_codec_amd.wavio.save_audio computes on the host (bit-exact; tests/test_kernels_gpu.py)
+ * n samples, any alignment (16-byte aligned spans take the vector path).
+ */
+int swc_pcm16_to_f32(const int16_t* pcm, float* out, int64_t n, void* stream);
+int swc_f32_to_pcm16(const float* x, int16_t* pcm, int64_t n, void* stream);
+
 
 #ifdef __cplusplus
 }

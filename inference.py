@@ -32,7 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from audiocodec.model import AudioCodec  # noqa: E402
-from simwhisper_codec_amd.wavio import find_audio_files, load_audio, save_audio  # noqa: E402
+from simwhisper_codec_amd.pipeline import HostStager  # noqa: E402
+from simwhisper_codec_amd.wavio import find_audio_files, load_audio, read_pcm16, save_audio, save_pcm16  # noqa: E402
 
 
 def set_logging(level="INFO"):
@@ -55,6 +56,9 @@ def build_parser():
     p.add_argument("--in_flight", type=int, default=2,
                    help="batches in flight on the GPU (simwhisper_codec_amd.pipeline.InFlight: consecutive batches overlap on "
                         "two streams; same output files, about 7 %% more throughput; 1 = one batch at a time)")
+    p.add_argument("--io_threads", type=int, default=8,
+                   help="threads that read and write audio files (the files of a batch are independent; one thread writes "
+                        "about 1 200 ten-second files per second, less than one GPU produces)")
     p.add_argument("--dist_backend", type=str, default="nccl", help="torch.distributed backend under torch.distributed.run "
                    "(nccl = RCCL; gloo moves the audio through host memory: tests)")
     return p
@@ -87,24 +91,63 @@ def main(argv=None):
     bs = args.batch_size
     batches = [audio_paths[i:i + bs] for i in range(0, len(audio_paths), bs)]
 
+    io = ThreadPoolExecutor(max_workers=max(1, args.io_threads))
+
+    stager = HostStager()
+
+    on_gpu = device.type == "cuda"
+
+    def load_one(path):
+        # a mono PCM16 file at the model's rate goes to the GPU as 16-bit samples (converted there: the same values);
+        # everything else (other widths, channels, rates, FLAC) is decoded to f32 here
+        pcm = read_pcm16(path, generator.input_sample_rate) if on_gpu else None
+        return pcm if pcm is not None else load_audio(path, target_sample_rate=generator.input_sample_rate).reshape(-1)
+
+    def save_one(item):
+        path, wav = item
+        out = os.path.join(args.output_dir, os.path.splitext(os.path.basename(path))[0] + ".wav")
+        if wav.dtype == torch.int16:
+            save_pcm16(out, wav, sample_rate=generator.output_sample_rate)
+        else:
+            save_audio(out, wav.reshape(1, -1), sample_rate=generator.output_sample_rate)
+
+    def stage_in(cpu_wavs):
+        if not on_gpu:
+            return cpu_wavs
+        if all(w.dtype == torch.int16 for w in cpu_wavs):
+            return stager.to_device_pcm16(cpu_wavs, device)
+        return stager.to_device([w if w.dtype == torch.float32 else w.to(torch.float32) * (1.0 / 32768.0) for w in cpu_wavs], device)
+
+    # wall seconds per stage, summed over the threads that run them (they overlap).  The launch threads (process) do nothing but
+    # launch: reading + staging runs in the loader thread, the device -> host copy + writing in the saver thread
+    spent = {"load+h2d": 0.0, "encode+decode": 0.0, "d2h+save": 0.0}
+
     def load(paths):
-        return [load_audio(p, target_sample_rate=generator.input_sample_rate).reshape(-1).pin_memory()
-                if device.type == "cuda" else load_audio(p, target_sample_rate=generator.input_sample_rate).reshape(-1)
-                for p in paths]
+        t = time.perf_counter()
+        wavs = stage_in(list(io.map(load_one, paths)))
+        if on_gpu:
+            torch.cuda.current_stream(device).synchronize()   # the staging buffer is re-used by the next batch
+        spent["load+h2d"] += time.perf_counter() - t
+        return wavs
 
     def save(paths, wavs):
-        for path, wav in zip(paths, wavs):
-            out = os.path.join(args.output_dir, os.path.splitext(os.path.basename(path))[0] + ".wav")
-            save_audio(out, wav.reshape(1, -1), sample_rate=generator.output_sample_rate)
+        t = time.perf_counter()
+        host = stager.to_host(wavs) if on_gpu else wavs        # (the batch's stream was synchronised before it was handed back)
+        list(io.map(save_one, zip(paths, host)))
+        spent["d2h+save"] += time.perf_counter() - t
 
     def process(model, item):
         """one batch on `model` (the generator or its replica), on the calling thread's stream"""
-        paths, cpu_wavs = item
+        paths, wav_list = item
         with torch.no_grad():
-            wav_list = [w.to(device, non_blocking=True) for w in cpu_wavs]
+            t1 = time.perf_counter()
             codes_list = model.encode(wav_list, overlap_seconds=10, device=device)["codes_list"]
             syn = model.decode(codes_list, overlap_seconds=10, device=device)["syn_wav_list"]
-            return paths, [c.shape[-1] for c in codes_list], [w.cpu() for w in syn]
+            out = stager.pcm16_on_device(syn) if on_gpu else [w.cpu() for w in syn]
+            if on_gpu:
+                torch.cuda.current_stream().synchronize()
+            spent["encode+decode"] += time.perf_counter() - t1
+            return paths, [c.shape[-1] for c in codes_list], out
 
     pipe = None
     if device.type == "cuda" and args.in_flight > 1 and len(batches) > 1:
@@ -142,9 +185,11 @@ def main(argv=None):
             pending_save.result()
     if pipe is not None:
         pipe.close()
+    io.shutdown()
     dt = time.perf_counter() - t0
     logging.info(f"All audio processing completed: {total_audio:.1f} s of audio in {dt:.2f} s "
                  f"({total_audio / max(dt, 1e-9):.1f} x real time incl. file IO)")
+    logging.info("stage wall seconds (overlapping threads): " + ", ".join(f"{k} {v:.2f}" for k, v in spent.items()))
 
 
 def main_distributed(args, world):
@@ -179,14 +224,30 @@ def main_distributed(args, world):
             batches = None
         nb = dp._share_ints([len(batches)] if rank == 0 else None)[0]
         total_audio, t0 = 0.0, time.perf_counter()
-        with ThreadPoolExecutor(max_workers=2) as pool, torch.no_grad():
+        with ThreadPoolExecutor(max_workers=2) as pool, ThreadPoolExecutor(max_workers=max(1, args.io_threads)) as io, \
+                torch.no_grad():
+            stager = HostStager()
+
+            def load_one(path):
+                pcm = read_pcm16(path, generator.input_sample_rate)
+                return pcm if pcm is not None else load_audio(path, target_sample_rate=generator.input_sample_rate).reshape(-1)
+
+            def save_one(item):
+                path, wav = item
+                out = os.path.join(args.output_dir, os.path.splitext(os.path.basename(path))[0] + ".wav")
+                save_pcm16(out, wav, sample_rate=generator.output_sample_rate)
+
+            def stage_in(cpu_wavs):
+                if all(w.dtype == torch.int16 for w in cpu_wavs):
+                    return stager.to_device_pcm16(cpu_wavs, device)
+                return stager.to_device([w if w.dtype == torch.float32 else w.to(torch.float32) * (1.0 / 32768.0)
+                                         for w in cpu_wavs], device)
+
             def load(paths):
-                return [load_audio(p, target_sample_rate=generator.input_sample_rate).reshape(-1).pin_memory() for p in paths]
+                return list(io.map(load_one, paths))
 
             def save(paths, wavs):
-                for path, wav in zip(paths, wavs):
-                    out = os.path.join(args.output_dir, os.path.splitext(os.path.basename(path))[0] + ".wav")
-                    save_audio(out, wav.reshape(1, -1), sample_rate=generator.output_sample_rate)
+                list(io.map(save_one, zip(paths, wavs)))
             nxt = pool.submit(load, batches[0]) if rank == 0 and nb else None
             pending = None
             for bi in range(nb):
@@ -195,11 +256,11 @@ def main_distributed(args, world):
                     logging.info(f"Processing batch {bi + 1}/{nb}, files: {batches[bi]}")
                     cpu_wavs = nxt.result()
                     nxt = pool.submit(load, batches[bi + 1]) if bi + 1 < nb else None
-                    wav_list = [w.to(device, non_blocking=True) for w in cpu_wavs]
+                    wav_list = stage_in(cpu_wavs)
                 out = dp.encode_decode(wav_list, overlap_seconds=10)
                 if rank == 0:
                     logging.info(f"Decoding completed, generated waveform lengths: {[len(w) for w in out['syn_wav_list']]} samples")
-                    host = [w.cpu() for w in out["syn_wav_list"]]
+                    host = stager.to_host(stager.pcm16_on_device(out["syn_wav_list"]))
                     total_audio += sum(len(w) for w in host) / generator.output_sample_rate
                     if pending is not None:
                         pending.result()

@@ -63,6 +63,8 @@ SIGNATURES = {
     "swc_cast_f32_f16s": [_P, _L, _P, _L, _I, _F, _P],
     "swc_cast_fp8": [_P, _I, _P, _L, _F, _P],
     "swc_gather_rows": [_P, _P, _P, _L, _I, _P],
+    "swc_pcm16_to_f32": [_P, _P, _L, _P],
+    "swc_f32_to_pcm16": [_P, _P, _L, _P],
     "swc_set_saturation_counter": [_P],
     "swc_delay_us": [_I, _P],
     "swc_pack_rows": [_P, _P, _P, _P, _I, _I, _L, _P],

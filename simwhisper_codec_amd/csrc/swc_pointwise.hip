@@ -1130,6 +1130,65 @@ extern "C" int swc_cast_fp8(const void* x, int32_t x_dtype, void* y, int64_t n, 
     return SWC_OK;
 }
 
+// ---------------------------------------------------------------- PCM16 <-> f32 (file IO around the path)
+// Both directions are HBM-bound streams (6 bytes per sample); 8 samples per thread, 16-byte accesses on the wide side.
+namespace {
+__global__ void pcm16_to_f32_kernel(const short* __restrict__ in, float* __restrict__ out, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n && ((reinterpret_cast<uintptr_t>(in + i) | reinterpret_cast<uintptr_t>(out + i)) & 15) == 0) {
+        const uint4 v = *reinterpret_cast<const uint4*>(in + i);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f[2 * k] = (float)(short)(w[k] & 0xFFFFu) * 0x1p-15f;
+            f[2 * k + 1] = (float)(short)(w[k] >> 16) * 0x1p-15f;
+        }
+        reinterpret_cast<float4*>(out + i)[0] = make_float4(f[0], f[1], f[2], f[3]);
+        reinterpret_cast<float4*>(out + i)[1] = make_float4(f[4], f[5], f[6], f[7]);
+    } else {
+        for (long k = i; k < n && k < i + 8; ++k) out[k] = (float)in[k] * 0x1p-15f;
+    }
+}
+__device__ __forceinline__ int pcm16_of(float x) {
+    // round(clip(x, -1, 1) * 32767), ties to even, every step in f32: numpy's result on the host (wavio.save_audio);
+    // a NaN sample (the path never produces one) becomes -32767 here
+    return __float2int_rn(__fmul_rn(fminf(fmaxf(x, -1.0f), 1.0f), 32767.0f));
+}
+__global__ void f32_to_pcm16_kernel(const float* __restrict__ in, short* __restrict__ out, long n) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n && ((reinterpret_cast<uintptr_t>(in + i) | reinterpret_cast<uintptr_t>(out + i)) & 15) == 0) {
+        const float4 a = reinterpret_cast<const float4*>(in + i)[0], b = reinterpret_cast<const float4*>(in + i)[1];
+        const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        unsigned w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            w[k] = ((unsigned)pcm16_of(f[2 * k]) & 0xFFFFu) | ((unsigned)pcm16_of(f[2 * k + 1]) << 16);
+        *reinterpret_cast<uint4*>(out + i) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+        for (long k = i; k < n && k < i + 8; ++k) out[k] = (short)pcm16_of(in[k]);
+    }
+}
+}  // namespace
+
+extern "C" int swc_pcm16_to_f32(const int16_t* pcm, float* out, int64_t n, void* stream) {
+    SWC_CHECK_ARG(n >= 0 && (n == 0 || (pcm && out)), "swc_pcm16_to_f32: bad args");
+    if (n == 0) return SWC_OK;
+    hipLaunchKernelGGL(pcm16_to_f32_kernel, dim3(nblk(nblk(n, 8), 256)), dim3(256), 0, (hipStream_t)stream, (const short*)pcm,
+                       out, (long)n);
+    SWC_CHECK_LAUNCH("swc_pcm16_to_f32");
+    return SWC_OK;
+}
+
+extern "C" int swc_f32_to_pcm16(const float* x, int16_t* pcm, int64_t n, void* stream) {
+    SWC_CHECK_ARG(n >= 0 && (n == 0 || (x && pcm)), "swc_f32_to_pcm16: bad args");
+    if (n == 0) return SWC_OK;
+    hipLaunchKernelGGL(f32_to_pcm16_kernel, dim3(nblk(nblk(n, 8), 256)), dim3(256), 0, (hipStream_t)stream, x, (short*)pcm,
+                       (long)n);
+    SWC_CHECK_LAUNCH("swc_f32_to_pcm16");
+    return SWC_OK;
+}
+
 // ---------------------------------------------------------------- valid-token packing
 // [B][T][row_bytes] padded rows -> packed rows: utterance b's first lens[b] rows land at row_start[b] (16-byte chunks).
 namespace {

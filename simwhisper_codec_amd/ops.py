@@ -270,6 +270,28 @@ def gather_rows(ptrs_dev, nbytes_dev, n_rows, ld_elems, dtype, device):
     return out
 
 
+def pcm16_to_f32(pcm):
+    """int16 device tensor -> f32 of the same shape, pcm * 2^-15 (include/swc.h swc_pcm16_to_f32)."""
+    lib = _lib.load()
+    _chk(pcm, "pcm16_to_f32 pcm", torch.int16)
+    if not pcm.is_contiguous():
+        raise _lib.SwcError("pcm16_to_f32: contiguous input expected")
+    out = torch.empty(pcm.shape, device=pcm.device, dtype=torch.float32)
+    _lib.check(lib.swc_pcm16_to_f32(_ptr(pcm), _ptr(out), pcm.numel(), _stream()), "swc_pcm16_to_f32")
+    return out
+
+
+def f32_to_pcm16(x):
+    """f32 device tensor -> int16 of the same shape, round(clip(x, -1, 1) * 32767) (include/swc.h swc_f32_to_pcm16)."""
+    lib = _lib.load()
+    _chk(x, "f32_to_pcm16 x", torch.float32)
+    if not x.is_contiguous():
+        raise _lib.SwcError("f32_to_pcm16: contiguous input expected")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.int16)
+    _lib.check(lib.swc_f32_to_pcm16(_ptr(x), _ptr(out), x.numel(), _stream()), "swc_f32_to_pcm16")
+    return out
+
+
 def set_saturation_counter(counters):
     """counters: int32/uint32 device tensor of 2 elements (or None): see swc_set_saturation_counter in include/swc.h.
     The pointer is per calling thread; the tensor must outlive its use."""

@@ -133,6 +133,40 @@ def _decode_flac(path):
     return out[:n], int(sr.value), int(bits.value)
 
 
+def read_pcm16(audio_path, target_sample_rate):
+    """The common case without any host arithmetic: a mono 16-bit PCM .wav already at target_sample_rate -> its samples as an
+    int16 tensor (T,) (a copy of the file's bytes), else None.  `samples * 2^-15` (ops.pcm16_to_f32 on the GPU) is then exactly
+    what load_audio returns for the same file."""
+    if os.path.splitext(audio_path)[1].lower() != ".wav":
+        return None
+    with open(audio_path, "rb") as f:
+        data = f.read()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        return None
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        if cid == b"fmt " and size >= 16:
+            fmt = struct.unpack("<HHIIHH", data[pos + 8:pos + 24])
+        elif cid == b"data":
+            pcm = (pos + 8, min(size, len(data) - pos - 8))
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None or fmt[0] != 1 or fmt[1] != 1 or fmt[2] != int(target_sample_rate) or fmt[5] != 16:
+        return None
+    return torch.from_numpy(np.frombuffer(data, dtype="<i2", count=pcm[1] // 2, offset=pcm[0]).copy())
+
+
+def save_pcm16(audio_outpath, pcm, sample_rate):
+    """int16 samples (tensor or array, any shape, mono) -> 16-bit PCM WAV: the file save_audio writes once the conversion
+    round(clip(x, -1, 1) * 32767) has been done elsewhere (ops.f32_to_pcm16 on the GPU)."""
+    raw = (pcm.detach().cpu().numpy() if isinstance(pcm, torch.Tensor) else np.asarray(pcm)).astype("<i2", copy=False).reshape(-1).tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(raw)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, 1, 1, int(sample_rate), int(sample_rate) * 2, 2, 16) + b"data" + struct.pack("<I", len(raw))
+    with open(audio_outpath, "wb") as f:
+        f.write(hdr + raw)
+    logging.info(f"Successfully saved audio at {audio_outpath}")
+
+
 def load_audio(audio_path, target_sample_rate):
     """-> FloatTensor (1, 1, T) at target_sample_rate, mono (helpers.py:77-94)."""
     ext = os.path.splitext(audio_path)[1].lower()
@@ -179,7 +213,8 @@ def resample(wav, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
 def save_audio(audio_outpath, audio_out, sample_rate):
     """audio_out: tensor (1, T) or (T,), float in [-1, 1] -> 16-bit PCM mono WAV (helpers.py:96-104)."""
     x = audio_out.detach().to("cpu", torch.float32).reshape(-1).numpy()
-    pcm = np.round(np.clip(x, -1.0, 1.0) * 32767.0).astype("<i2").tobytes()
+    # (np.minimum / np.maximum: the same values as np.clip at a quarter of its time on 160 000 samples)
+    pcm = np.round(np.minimum(np.maximum(x, np.float32(-1.0)), np.float32(1.0)) * np.float32(32767.0)).astype("<i2").tobytes()
     hdr = b"RIFF" + struct.pack("<I", 36 + len(pcm)) + b"WAVE" + b"fmt " + struct.pack(
         "<IHHIIHH", 16, 1, 1, int(sample_rate), int(sample_rate) * 2, 2, 16) + b"data" + struct.pack("<I", len(pcm))
     with open(audio_outpath, "wb") as f:

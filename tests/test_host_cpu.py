@@ -278,3 +278,31 @@ def test_wav_reader_against_the_reference_assets():
         assert zlib.crc32(pcm.tobytes()) & 0xFFFFFFFF == r["crc32_pcm"], name
         y = wavio.load_audio(os.path.join(ref_dir, name), 16000)   # the CLI's loader: mono, 16 kHz
         assert y.reshape(-1).shape[0] == -(-r["frames"] * 16000 // r["rate"])
+
+
+def test_pcm16_fast_path_files_equal_the_float_path(tmp_path):
+    """wavio.read_pcm16 / save_pcm16 (what inference.py uses when the conversion runs on the GPU): the samples are those of
+    load_audio times 32768, the written file is save_audio's byte for byte, and anything but mono PCM16 at the asked rate
+    is declined (-> the float path)."""
+    import numpy as np
+    import torch
+    from simwhisper_codec_amd import wavio
+    x = torch.rand(1, 4001) * 2.4 - 1.2
+    p = str(tmp_path / "a.wav")
+    wavio.save_audio(p, x, 16000)
+    pcm = wavio.read_pcm16(p, 16000)
+    assert pcm.dtype == torch.int16 and pcm.shape == (4001,)
+    f = wavio.load_audio(p, 16000).reshape(-1)
+    assert torch.equal(pcm.to(torch.float32) / 32768.0, f)
+    want = torch.from_numpy(np.round(np.clip(x.reshape(-1).numpy(), -1.0, 1.0) * 32767.0).astype("<i2"))
+    assert torch.equal(pcm, want)
+    wavio.save_pcm16(str(tmp_path / "b.wav"), pcm, 16000)
+    assert (tmp_path / "b.wav").read_bytes() == (tmp_path / "a.wav").read_bytes()
+    assert wavio.read_pcm16(p, 24000) is None                     # another rate: resampled on the host
+    import struct
+    raw = bytearray((tmp_path / "a.wav").read_bytes())
+    raw[22:24] = struct.pack("<H", 2)                             # claims two channels
+    (tmp_path / "c.wav").write_bytes(bytes(raw))
+    assert wavio.read_pcm16(str(tmp_path / "c.wav"), 16000) is None
+    (tmp_path / "d.flac").write_bytes(b"fLaC")
+    assert wavio.read_pcm16(str(tmp_path / "d.flac"), 16000) is None

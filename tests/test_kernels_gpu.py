@@ -769,3 +769,24 @@ def test_convnext_block_fused(B, T, I):
     e_pair = float((out.cpu().double() - x2.cpu().double()).abs().max()) / scale
     assert e_ref < 1.5e-2, e_ref      # bf16 operands (y and the GELU output are rounded to bf16)
     assert e_pair < 2e-3, e_pair      # same arithmetic as the two-kernel form up to the bf16 rounding of y at ties
+
+
+@pytest.mark.parametrize("n,off", [(0, 0), (1, 0), (7, 0), (8, 0), (160000, 0), (160003, 0), (4099, 3), (65536, 5)])
+def test_pcm16_conversions_match_the_host(n, off):
+    """swc_pcm16_to_f32 / swc_f32_to_pcm16 (include/swc.h; the file loop of inference.py) against the host arithmetic of
+    wavio.load_audio / wavio.save_audio, bit for bit, at aligned and unaligned starts and lengths."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(n + off)
+    pcm = torch.randint(-32768, 32768, (n + off,), generator=g, dtype=torch.int32).to(torch.int16)
+    if n + off >= 4:
+        pcm[off:off + 2] = torch.tensor([-32768, 32767], dtype=torch.int16)[: max(0, min(2, n))]
+    got = ops.pcm16_to_f32(pcm.to(DEV)[off:].contiguous() if off == 0 else pcm.to(DEV)[off:]).cpu()
+    want = torch.from_numpy(pcm[off:].numpy().astype(np.float32) / 32768.0)
+    assert got.dtype == torch.float32 and torch.equal(got, want)
+    x = (torch.rand(n + off, generator=g) * 2.6 - 1.3)
+    k = min(n + off, 12)   # ties, the clip points and just beyond them
+    x[:k] = torch.tensor([0.5 / 32767, 1.5 / 32767, 2.5 / 32767, -0.5 / 32767, 1.0, -1.0, 1.0000001, -1.0000001, 3.0, -3.0, 0.0,
+                          32766.5 / 32767])[:k]
+    got = ops.f32_to_pcm16(x.to(DEV)[off:]).cpu()
+    want = torch.from_numpy(np.round(np.clip(x[off:].numpy(), -1.0, 1.0) * 32767.0).astype("<i2"))
+    assert got.dtype == torch.int16 and torch.equal(got, want)

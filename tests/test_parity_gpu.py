@@ -306,6 +306,10 @@ def test_cli_end_to_end(tmp_path):
     for k, r in zip(("a.wav", "b.wav"), ref):
         y = load_audio(str(outd / k), 16000).reshape(-1)
         assert (y - r.cpu().clamp(-1, 1)).abs().max().item() <= 1.0 / 32767 + 1e-6
+        # the CLI moves 16-bit samples over PCIe and converts on the GPU (swc_pcm16_to_f32 / swc_f32_to_pcm16): the file must be
+        # byte for byte the one the host conversion of the same waveform writes
+        save_audio(str(tmp_path / "host.wav"), r.reshape(1, -1), 16000)
+        assert (outd / k).read_bytes() == (tmp_path / "host.wav").read_bytes()
 
 
 def test_vocos_two_stream_chains_are_exact():
