@@ -18,6 +18,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA(acc) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define MFMA16B(acc) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(ab), "v"(bb))
+#define MFMA32B(acc) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(ab), "v"(bb))
 #define FMA(x) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(c1), "v"(c2))
 #define EXP(x) asm volatile("v_exp_f32 %0, %0" : "+v"(x))
 
@@ -31,6 +35,15 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, unsigned long lo
     float x[12];
     for (int i = 0; i < 12; ++i) x[i] = threadIdx.x * 0.01f + i;
     float c1 = 0.999f, c2 = 0.001f;
+    // pseudo-random bf16 operands (the clock the chip holds depends on the data: zeros run faster than random bits)
+    bf16x8 ab, bb;
+    {
+        unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+        unsigned short t[16];
+        for (int i = 0; i < 16; ++i) { h = h * 1664525u + 1013904223u; t[i] = (unsigned short)(0x3c00u | ((h >> 9) & 0x83ffu)); }
+        for (int i = 0; i < 8; ++i) { ab[i] = __builtin_bit_cast(__bf16, t[i]); bb[i] = __builtin_bit_cast(__bf16, t[8 + i]); }
+    }
+    f32x16 big0 = {0}, big1 = big0, big2 = big0, big3 = big0;
     const int wave = threadIdx.x >> 6;
     const bool second = wave >= 4;
     for (int it = 0; it < iters; ++it) {
@@ -94,6 +107,12 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, unsigned long lo
 #pragma unroll
             for (int r = 0; r < 5; ++r) { MFMA(acc0); MFMA(acc1); MFMA(acc2); }
             MFMA(acc3);
+        } else if (MODE == 13) {  // 16 x 16x16x32 bf16, random operands, 4 accumulators
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { MFMA16B(acc0); MFMA16B(acc1); MFMA16B(acc2); MFMA16B(acc3); }
+        } else if (MODE == 14) {  // 8 x 32x32x16 bf16 (the same flops), random operands, 4 accumulators
+#pragma unroll
+            for (int r = 0; r < 2; ++r) { MFMA32B(big0); MFMA32B(big1); MFMA32B(big2); MFMA32B(big3); }
         } else if (MODE == 5) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -115,6 +134,7 @@ __global__ __launch_bounds__(512) void k(float* out, int iters, unsigned long lo
     float s = 0;
     for (int i = 0; i < 12; ++i) s += x[i];
     for (int i = 0; i < 4; ++i) s += acc0[i] + acc1[i] + acc2[i] + acc3[i];
+    for (int i = 0; i < 16; ++i) s += big0[i] + big1[i] + big2[i] + big3[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -159,6 +179,10 @@ int main() {
     run<12>("16 MFMA on three accumulators", 256, d, cyc);
     run<10>("16 MFMA on ONE accumulator, two waves per SIMD", 512, d, cyc);
     run<11>("16 MFMA on two accumulators, two waves per SIMD", 512, d, cyc);
+    run<13>("16 MFMA 16x16x32 bf16, random operands", 256, d, cyc);
+    run<14>("8 MFMA 32x32x16 bf16 (same flops), random operands", 256, d, cyc);
+    run<13>("16 MFMA 16x16x32 bf16, random, two waves per SIMD", 512, d, cyc);
+    run<14>("8 MFMA 32x32x16 bf16, random, two waves per SIMD", 512, d, cyc);
     run<7>("16 x (MFMA + 2 v_fma) in one wave", 256, d, cyc);
     run<8>("two waves per SIMD: 16 MFMA at s_setprio 3 | 48 v_fma", 512, d, cyc);
     run<9>("two waves per SIMD, both 16 x (MFMA + 3 v_fma)", 512, d, cyc);
