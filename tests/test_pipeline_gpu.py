@@ -57,3 +57,44 @@ def test_replica_cannot_repack():
     r = m.replica()
     with pytest.raises(SwcError):
         r.precision = "bf16"
+
+
+def test_host_stager_moves_the_same_values_as_the_per_file_path(tmp_path):
+    """pipeline.HostStager (the file loop of inference.py): a ragged batch incl. an empty utterance staged as 16-bit samples and
+    converted on the GPU equals load_audio's floats bit for bit; decode()'s rows converted on the GPU and copied once equal the
+    host conversion of wavio.save_audio; the f32 staging path equals a plain copy; lists without a common buffer fall back."""
+    import numpy as np
+    from simwhisper_codec_amd import synth, wavio
+    from simwhisper_codec_amd.pipeline import HostStager
+    st = HostStager()
+    lens = [16000, 0, 4803, 1, 31999]
+    pcm, flt = [], []
+    for i, n in enumerate(lens):
+        p = str(tmp_path / f"u{i}.wav")
+        wavio.save_audio(p, (synth.synth_audio(n, index=40 + i, kind="speech") * 3.0).reshape(1, -1), 16000)   # clips in places
+        pcm.append(wavio.read_pcm16(p, 16000))
+        flt.append(wavio.load_audio(p, 16000).reshape(-1))
+    dev = torch.device("cuda", 0)
+    got = st.to_device_pcm16(pcm, dev)
+    assert [int(g.numel()) for g in got] == lens and all(g.dtype == torch.float32 for g in got)
+    for g, f in zip(got, flt):
+        assert torch.equal(g.cpu(), f)
+        assert g.data_ptr() % 16 == 0 or g.numel() == 0
+    got = st.to_device(flt, dev)
+    for g, f in zip(got, flt):
+        assert torch.equal(g.cpu(), f)
+    # rows of one padded buffer (what decode() returns), values beyond +-1 and exact ties included
+    base = torch.randn(4, 5000, device=dev) * 0.7
+    base[0, :6] = torch.tensor([1.5, -1.5, 0.5 / 32767, 1.5 / 32767, -2.5 / 32767, 1.0], device=dev)
+    rows = [base[i, :n] for i, n in enumerate([5000, 0, 1234, 4999])]
+    dev16 = st.pcm16_on_device(rows)
+    assert all(d._base is dev16[0]._base for d in dev16)
+    host = st.to_host(dev16)
+    for r, h in zip(rows, host):
+        want = torch.from_numpy(np.round(np.clip(r.cpu().numpy(), -1.0, 1.0) * 32767.0).astype("<i2"))
+        assert h.dtype == torch.int16 and torch.equal(h, want)
+    # no common buffer: per-tensor fall-back, same values
+    loose = [torch.randn(100, device=dev), torch.randn(7, device=dev)]
+    for r, h in zip(loose, st.to_host(st.pcm16_on_device(loose))):
+        assert torch.equal(h, torch.from_numpy(np.round(np.clip(r.cpu().numpy(), -1.0, 1.0) * 32767.0).astype("<i2")))
+    assert st.to_host([]) == [] and st.pcm16_on_device([]) == []
