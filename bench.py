@@ -147,8 +147,8 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(gp, sd, shapes, seconds, threads):
-    """oracle/ref_cpu.py on the host cores: per shape 1 warm-up + 3 timed encode+decode passes, median."""
+def cpu_baseline(gp, sd, shapes, seconds, threads, timed=3):
+    """oracle/ref_cpu.py on the host cores: per shape 1 warm-up + `timed` timed encode+decode passes, median."""
     from oracle.ref_cpu import Oracle
     torch.set_num_threads(threads)
     ora = Oracle(gp, sd)
@@ -158,7 +158,7 @@ def cpu_baseline(gp, sd, shapes, seconds, threads):
     for n_utt in shapes:
         wavs = bench_inputs(n_utt, int(seconds * 16000))
         times = []
-        for it in range(4):
+        for it in range(1 + timed):
             t0 = time.perf_counter()
             codes = ora.encode(wavs)["codes_list"]
             wav = ora.decode(codes)["syn_wav_list"]
@@ -171,7 +171,7 @@ def cpu_baseline(gp, sd, shapes, seconds, threads):
                     "pass_s": [round(t, 2) for t in times]})
     head = res[-1]
     return {"value": head["audio-s/s"], "unit": "audio-s/s", "cores": threads, "kind": "port", "cpu": cpu_model(),
-            "sample": f"{head['batch']} x {seconds:g} s utterances (same generator as the GPU run), 1 warm-up + 3 timed "
+            "sample": f"{head['batch']} x {seconds:g} s utterances (same generator as the GPU run), 1 warm-up + {timed} timed "
                       f"encode+decode passes, median; fp32, oracle/ref_cpu.py (reference algorithm incl. 30 s padding); "
                       f"{time.perf_counter() - t_all:.0f} s of CPU work",
             "shapes": res}, first
@@ -217,7 +217,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--precision", default="mixed", choices=["fp32", "mixed", "mixed_f32", "bf16", "fp8"])
     ap.add_argument("--cpu-baseline", default="sample", choices=["sample", "small", "full", "off"],
-                    help="sample: B=8 x 10 s, BASELINE.json configs[1]'s shape (~60 s of CPU work); small: 2 utterances "
+                    help="sample: B=8 x 10 s, BASELINE.json configs[1]'s shape (~25 s of CPU work); small: 2 utterances "
                          "(~15 s); full: B=8 and B=32 as BASELINE.md 2 (minutes)")
     ap.add_argument("--no-timer", action="store_true", help="no per-launch event pairs (no roofline object)")
     ap.add_argument("--no-dist", action="store_true", help="N=1 only: skip the process group and the scatter/gather measurement")
@@ -292,7 +292,8 @@ def main():
     if world == 1 and rank == 0 and args.cpu_baseline != "off":
         threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
         shapes = {"sample": [min(8, args.batch)], "small": [min(2, args.batch)], "full": [8, 32]}[args.cpu_baseline]
-        cpu_res, first = cpu_baseline(gp, sd, shapes, args.seconds, threads)
+        # (sample: one timed pass after the warm-up, ~25 s of CPU work in all; passes repeat within 3 %: profiles/r03_d_bench.json.log)
+        cpu_res, first = cpu_baseline(gp, sd, shapes, args.seconds, threads, timed=1 if args.cpu_baseline == "sample" else 3)
         expect = {"source": "oracle/ref_cpu.py (CPU, fp32)", "codes": first["codes"], "wav": first["wav"]}
     else:
         r0 = model.encode(mine[:1], overlap_seconds=10, device=dev)["codes_list"]
