@@ -473,7 +473,8 @@ def main():
                 "configs[1] batch=8x10s bf16": (8, 10.0, "bf16", 10),
                 "configs[2] batch=32x30s mixed": (32, 30.0, "mixed", 4),
                 "configs[4] batch=32x10s fp8 encoder linears": (32, 10.0, "fp8", 8),
-                "batch=32x10s fp32 (the reference's arithmetic)": (32, 10.0, "fp32", 3)}.items():
+                "batch=32x10s fp32 (the reference's arithmetic)": (32, 10.0, "fp32", 3),
+                "batch=32x10s mixed_f32 (exact-f32 encoder, the range guard's fallback)": (32, 10.0, "mixed_f32", 4)}.items():
             try:
                 mdl = build(oprec)
                 w = [x.to(dev) for x in bench_inputs(ob, int(osec * 16000))]
