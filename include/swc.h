@@ -231,6 +231,13 @@ int swc_fsq_encode(const float* z, int64_t ldz, float* zq, int32_t* codes, const
                    void* stream);
 int swc_fsq_decode(const int64_t* codes, float* zq, int64_t ldq, const int32_t* lens, int32_t B,
                    int32_t T, int32_t G, void* stream);
+/* the same with the levels of the four channels of a group given by the caller (HOST pointer, 4 values in 2..1024 whose product
+ * fits an int32 code: quantizer.py:47-120 is config-driven); swc_fsq_encode / swc_fsq_decode are these with {8, 7, 6, 6} */
+int swc_fsq_encode_levels(const float* z, int64_t ldz, float* zq, int32_t* codes, const int32_t* lens,
+                          const float* consts_host12, const int32_t* levels_host4, int32_t B, int32_t T,
+                          int32_t t_pad, int32_t G, void* stream);
+int swc_fsq_decode_levels(const int64_t* codes, float* zq, int64_t ldq, const int32_t* lens,
+                          const int32_t* levels_host4, int32_t B, int32_t T, int32_t G, void* stream);
 
 /*
  * Whisper log-mel front end (feature_extractor.py:86-112,207-214), three steps

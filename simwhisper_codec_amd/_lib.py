@@ -50,6 +50,8 @@ SIGNATURES = {
     "swc_snake_aa": [_P, _P, _P, _P, C.POINTER(_F), _I, _I, _I, _I, _P],
     "swc_fsq_encode": [_P, _L, _P, _P, _P, C.POINTER(_F), _I, _I, _I, _I, _P],
     "swc_fsq_decode": [_P, _P, _L, _P, _I, _I, _I, _P],
+    "swc_fsq_encode_levels": [_P, _L, _P, _P, _P, C.POINTER(_F), C.POINTER(C.c_int32), _I, _I, _I, _I, _P],
+    "swc_fsq_decode_levels": [_P, _P, _L, _P, C.POINTER(C.c_int32), _I, _I, _I, _P],
     "swc_mel_frames": [_P, _L, _P, _I, _P, _I, _I, _P],
     "swc_mel_power": [_P, _L, _P, _L, _L, _P],
     "swc_mel_logmax": [_P, _L, _P, _I, _I, _I, _P],

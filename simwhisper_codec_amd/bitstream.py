@@ -19,7 +19,8 @@ GROUPS, BITS, FRAME_BYTES = 8, 11, 11
 
 
 def pack_codes(codes):
-    """codes: device IntTensor (8, T) with values < 2016 -> device ByteTensor (11 * T,)."""
+    """codes: device IntTensor (8, T) with values < 2048 (11 bits: the shipped [8, 7, 6, 6] levels give 2016 codes per group; a
+    config with a larger codebook or another group count needs another container) -> device ByteTensor (11 * T,)."""
     lib = _lib.load()
     if codes.dim() != 2 or codes.shape[0] != GROUPS:
         raise _lib.SwcError(f"pack_codes: expected ({GROUPS}, T) codes, got {tuple(codes.shape)}")

@@ -163,8 +163,10 @@ class AudioCodec(nn.Module):
         q = gp["quantizer"]
         self.num_groups = q["num_groups"]
         self.codebook_dim_per_group = len(q["num_levels_per_group"])
-        if list(q["num_levels_per_group"]) != [8, 7, 6, 6]:
-            raise SwcError("the FSQ kernels are built for num_levels_per_group = [8, 7, 6, 6]")
+        self.fsq_levels = tuple(int(v) for v in q["num_levels_per_group"])
+        if len(self.fsq_levels) != 4 or any(v < 2 or v > 1024 for v in self.fsq_levels) or math.prod(self.fsq_levels) >= 2 ** 31:
+            raise SwcError("the FSQ kernels take groups of 4 channels with 2..1024 levels each and an int32 code per group "
+                           f"(num_levels_per_group = {list(self.fsq_levels)})")
         enc = dict(gp["acoustic_encoder"])
         # keys the reference pops before building the encoder (model.py:35-39)
         self.freeze_acoustic_encoder_flag = enc.pop("freeze", False)
@@ -1000,7 +1002,7 @@ class AudioCodec(nn.Module):
             z, Tds, lat = self._encode_mel(mel, Tm, spec.MEL_FRAMES // 2, tok, P)
             t_pad = spec.cdiv(spec.MEL_FRAMES // 2, P.stack)  # 375: the reference always returns the padded length
             lat_dev = self._dev_ints(lat, dev)
-            zq, codes = ops.fsq_encode(z, P.lat, lat_dev, P.fsq, B=B, T=Tds, t_pad=t_pad, G=self.num_groups)
+            zq, codes = ops.fsq_encode(z, P.lat, lat_dev, P.fsq, B=B, T=Tds, t_pad=t_pad, G=self.num_groups, levels=self.fsq_levels)
             return {"zq": zq.transpose(1, 2), "codes": codes, "codes_lengths": lat_dev.long()}
         return self._guarded_encode(run)
 
@@ -1016,7 +1018,7 @@ class AudioCodec(nn.Module):
         lat = [int(v) for v in (codes_lengths.tolist() if torch.is_tensor(codes_lengths) else codes_lengths)]
         dev = codes.device
         lat_dev = self._dev_ints(lat, dev)
-        zq = ops.fsq_decode(codes.to(torch.int64).contiguous(), lat_dev, B=B, T=T, G=G)
+        zq = ops.fsq_decode(codes.to(torch.int64).contiguous(), lat_dev, B=B, T=T, G=G, levels=self.fsq_levels)
         kf = None
         if _keep_samples is not None:
             hop = self.generator_params["vocos"]["hop_size"]
@@ -1266,7 +1268,7 @@ class AudioCodec(nn.Module):
             # the trimmed stem needs frames up to 2*max(tok): the given T is the true right boundary
             z, Tds, lat = self._encode_mel(self._cast(mel32, P.c1dt), T, t_full, tok, P)
             lat_dev = self._dev_ints(lat, dev)
-            zq, _ = ops.fsq_encode(z, P.lat, lat_dev, P.fsq, B=B, T=Tds, t_pad=t_lat, G=self.num_groups)
+            zq, _ = ops.fsq_encode(z, P.lat, lat_dev, P.fsq, B=B, T=Tds, t_pad=t_lat, G=self.num_groups, levels=self.fsq_levels)
             return zq, lat, lat_dev
         zq, lat, lat_dev = self._guarded_encode(run)
         P = self._packed()

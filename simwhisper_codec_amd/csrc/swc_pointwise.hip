@@ -486,8 +486,7 @@ __global__ __launch_bounds__(256) void snake_aa_kernel(const float* __restrict__
 }
 
 // ----------------------------------------------------------------------- FSQ
-struct FsqC { float scale[4], offset[4], shift[4]; };
-__constant__ const int kLevels[4] = {8, 7, 6, 6};
+struct FsqC { float scale[4], offset[4], shift[4]; int levels[4]; };
 
 __global__ void fsq_encode_kernel(const float* __restrict__ z, long ldz, float* __restrict__ zq,
                                   int* __restrict__ codes, const int* __restrict__ lens, int B, int T,
@@ -507,13 +506,13 @@ __global__ void fsq_encode_kernel(const float* __restrict__ z, long ldz, float* 
         int base = 1;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int half = kLevels[d] / 2;
+            const int half = K.levels[d] / 2;
             const float th = (float)tanh((double)__fadd_rn(in[d], K.shift[d]));
             const float comp = __fsub_rn(__fmul_rn(K.scale[d], th), K.offset[d]);
             const float c = rintf(comp);  // half-to-even == torch.round
             q[d] = __fdiv_rn(c, (float)half);
             idx += ((int)c + half) * base;
-            base *= kLevels[d];
+            base *= K.levels[d];
         }
     }
     *reinterpret_cast<float4*>(zq + ((long)b * t_pad + t) * (4L * G) + 4 * g) = make_float4(q[0], q[1], q[2], q[3]);
@@ -521,7 +520,7 @@ __global__ void fsq_encode_kernel(const float* __restrict__ z, long ldz, float* 
 }
 
 __global__ void fsq_decode_kernel(const long long* __restrict__ codes, float* __restrict__ zq, long ldq,
-                                  const int* __restrict__ lens, int B, int T, int G) {
+                                  const int* __restrict__ lens, int B, int T, int G, FsqC K) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int ng = (int)(ldq / 4);  // groups incl. zero padding columns
     const long total = (long)B * T * ng;
@@ -535,15 +534,15 @@ __global__ void fsq_decode_kernel(const long long* __restrict__ codes, float* __
         long long base = 1;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int half = kLevels[d] / 2;
+            const int half = K.levels[d] / 2;
             // torch's `//` and `%` (quantizer.py:214-216) round towards -inf: identical to C for valid codes, and for
             // out-of-range / negative ones the same wrapped level instead of C's truncation
             long long qd = idx / base;
             if (idx % base < 0) --qd;
-            long long nn = qd % kLevels[d];
-            if (nn < 0) nn += kLevels[d];
+            long long nn = qd % K.levels[d];
+            if (nn < 0) nn += K.levels[d];
             q[d] = __fdiv_rn((float)(nn - half), (float)half);
-            base *= kLevels[d];
+            base *= K.levels[d];
         }
     }
     *reinterpret_cast<float4*>(zq + ((long)b * T + t) * ldq + 4 * g) = make_float4(q[0], q[1], q[2], q[3]);
@@ -912,12 +911,22 @@ extern "C" int swc_snake_aa(const float* x, void* y, const float* alpha, const f
     return SWC_OK;
 }
 
-extern "C" int swc_fsq_encode(const float* z, int64_t ldz, float* zq, int32_t* codes, const int32_t* lens,
-                              const float* consts_host12, int32_t B, int32_t T, int32_t t_pad, int32_t G,
-                              void* stream) {
-    SWC_CHECK_ARG(z && zq && codes && lens && consts_host12, "swc_fsq_encode: null pointer");
+static bool fsq_levels_ok(const int32_t* lv) {
+    long prod = 1;
+    for (int i = 0; i < 4; ++i) {
+        if (lv[i] < 2 || lv[i] > 1024) return false;
+        prod *= lv[i];
+    }
+    return prod < (1L << 31);   // the index of a group is an int32 code
+}
+
+extern "C" int swc_fsq_encode_levels(const float* z, int64_t ldz, float* zq, int32_t* codes, const int32_t* lens,
+                                     const float* consts_host12, const int32_t* levels_host4, int32_t B, int32_t T,
+                                     int32_t t_pad, int32_t G, void* stream) {
+    SWC_CHECK_ARG(z && zq && codes && lens && consts_host12 && levels_host4, "swc_fsq_encode: null pointer");
     SWC_CHECK_ARG(G > 0 && ldz >= 4L * G && ldz % 4 == 0 && t_pad >= T, "swc_fsq_encode: bad shape");
     SWC_CHECK_ARG(aligned16(z) && aligned16(zq), "swc_fsq_encode: unaligned");
+    SWC_CHECK_ARG(fsq_levels_ok(levels_host4), "swc_fsq_encode: levels must be 4 values in 2..1024 whose product fits an int32 code");
     const long total = (long)B * t_pad * G;
     if (total <= 0) return SWC_OK;
     FsqC K;
@@ -925,6 +934,7 @@ extern "C" int swc_fsq_encode(const float* z, int64_t ldz, float* zq, int32_t* c
         K.scale[i] = consts_host12[i];
         K.offset[i] = consts_host12[4 + i];
         K.shift[i] = consts_host12[8 + i];
+        K.levels[i] = levels_host4[i];
     }
     hipLaunchKernelGGL(fsq_encode_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream, z, (long)ldz,
                        zq, codes, lens, B, T, t_pad, G, K);
@@ -932,17 +942,33 @@ extern "C" int swc_fsq_encode(const float* z, int64_t ldz, float* zq, int32_t* c
     return SWC_OK;
 }
 
-extern "C" int swc_fsq_decode(const int64_t* codes, float* zq, int64_t ldq, const int32_t* lens, int32_t B,
-                              int32_t T, int32_t G, void* stream) {
-    SWC_CHECK_ARG(codes && zq && lens, "swc_fsq_decode: null pointer");
+extern "C" int swc_fsq_decode_levels(const int64_t* codes, float* zq, int64_t ldq, const int32_t* lens,
+                                     const int32_t* levels_host4, int32_t B, int32_t T, int32_t G, void* stream) {
+    SWC_CHECK_ARG(codes && zq && lens && levels_host4, "swc_fsq_decode: null pointer");
     SWC_CHECK_ARG(G > 0 && ldq >= 4L * G && ldq % 4 == 0, "swc_fsq_decode: bad shape");
     SWC_CHECK_ARG(aligned16(zq), "swc_fsq_decode: unaligned");
+    SWC_CHECK_ARG(fsq_levels_ok(levels_host4), "swc_fsq_decode: levels must be 4 values in 2..1024 whose product fits an int32 code");
     const long total = (long)B * T * (ldq / 4);
     if (total <= 0) return SWC_OK;
+    FsqC K = {};
+    for (int i = 0; i < 4; ++i) K.levels[i] = levels_host4[i];
     hipLaunchKernelGGL(fsq_decode_kernel, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const long long*)codes, zq, (long)ldq, lens, B, T, G);
+                       (const long long*)codes, zq, (long)ldq, lens, B, T, G, K);
     SWC_CHECK_LAUNCH("swc_fsq_decode");
     return SWC_OK;
+}
+
+static const int32_t kShippedLevels[4] = {8, 7, 6, 6};   // config/SimWhisperCodec.yaml
+
+extern "C" int swc_fsq_encode(const float* z, int64_t ldz, float* zq, int32_t* codes, const int32_t* lens,
+                              const float* consts_host12, int32_t B, int32_t T, int32_t t_pad, int32_t G,
+                              void* stream) {
+    return swc_fsq_encode_levels(z, ldz, zq, codes, lens, consts_host12, kShippedLevels, B, T, t_pad, G, stream);
+}
+
+extern "C" int swc_fsq_decode(const int64_t* codes, float* zq, int64_t ldq, const int32_t* lens, int32_t B,
+                              int32_t T, int32_t G, void* stream) {
+    return swc_fsq_decode_levels(codes, zq, ldq, lens, kShippedLevels, B, T, G, stream);
 }
 
 extern "C" int swc_mel_frames(const float* wav, int64_t ld_wav, const int32_t* n, int32_t n_pad, float* frames,

@@ -157,23 +157,28 @@ def snake_aa(x, alpha, beta, filt12, *, B, T, C_, out=None, out_dtype=torch.floa
     return out
 
 
-def fsq_encode(z, ldz, lens, consts12, *, B, T, t_pad, G):
+FSQ_LEVELS = (8, 7, 6, 6)  # config/SimWhisperCodec.yaml; any four levels work (swc_fsq_*_levels)
+
+
+def fsq_encode(z, ldz, lens, consts12, *, B, T, t_pad, G, levels=FSQ_LEVELS):
     lib = _lib.load()
     _chk(z, "fsq_encode z", torch.float32); _chk(lens, "fsq_encode lens", torch.int32)
     zq = torch.empty((B, t_pad, 4 * G), device=z.device, dtype=torch.float32)
     codes = torch.empty((G, B, t_pad), device=z.device, dtype=torch.int32)
     k = (C.c_float * 12)(*[float(v) for v in consts12])
-    _lib.check(lib.swc_fsq_encode(_ptr(z), ldz, _ptr(zq), _ptr(codes), _ptr(lens), k, B, T, t_pad, G, _stream()),
-               "swc_fsq_encode")
+    lv = (C.c_int32 * 4)(*[int(v) for v in levels])
+    _lib.check(lib.swc_fsq_encode_levels(_ptr(z), ldz, _ptr(zq), _ptr(codes), _ptr(lens), k, lv, B, T, t_pad, G, _stream()),
+               "swc_fsq_encode_levels")
     return zq, codes
 
 
-def fsq_decode(codes, lens, *, B, T, G, ldq=None):
+def fsq_decode(codes, lens, *, B, T, G, ldq=None, levels=FSQ_LEVELS):
     lib = _lib.load()
     _chk(codes, "fsq_decode codes", torch.int64); _chk(lens, "fsq_decode lens", torch.int32)
     ldq = 4 * G if ldq is None else ldq
     zq = torch.empty((B, T, ldq), device=codes.device, dtype=torch.float32)
-    _lib.check(lib.swc_fsq_decode(_ptr(codes), _ptr(zq), ldq, _ptr(lens), B, T, G, _stream()), "swc_fsq_decode")
+    lv = (C.c_int32 * 4)(*[int(v) for v in levels])
+    _lib.check(lib.swc_fsq_decode_levels(_ptr(codes), _ptr(zq), ldq, _ptr(lens), lv, B, T, G, _stream()), "swc_fsq_decode_levels")
     return zq
 
 

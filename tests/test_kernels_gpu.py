@@ -790,3 +790,43 @@ def test_pcm16_conversions_match_the_host(n, off):
     got = ops.f32_to_pcm16(x.to(DEV)[off:]).cpu()
     want = torch.from_numpy(np.round(np.clip(x[off:].numpy(), -1.0, 1.0) * 32767.0).astype("<i2"))
     assert got.dtype == torch.int16 and torch.equal(got, want)
+
+
+@pytest.mark.parametrize("levels", [(5, 5, 5, 4), (16, 3, 2, 9), (2, 2, 2, 2), (8, 8, 8, 5)])
+def test_fsq_other_level_sets(levels):
+    """swc_fsq_encode_levels / swc_fsq_decode_levels with level sets other than the shipped [8, 7, 6, 6] (the reference's
+    quantiser is config-driven, quantizer.py:47-120) against the reference's formulas restated in torch (oracle/ref_cpu.py
+    fsq_encode / fsq_decode): codes and quantised values bit for bit, every code of the codebook decoded, masking kept."""
+    from simwhisper_codec_amd import spec
+    ops = _ops()
+    lv = torch.tensor(levels)
+    k12 = spec.fsq_constants(list(levels), 1e-3)
+    scale, offset, shift = (torch.tensor(k12[i:i + 4]) for i in (0, 4, 8))
+    half = (lv // 2).float()
+    base = torch.cumprod(torch.cat([torch.ones(1, dtype=torch.long), lv[:-1]]), 0)
+    B, T, G, t_pad = 2, 40, 3, 48
+    g = torch.Generator().manual_seed(sum(levels))
+    z = torch.randn(B, T, 4 * G, generator=g) * 1.5
+    lens = torch.tensor([40, 17], dtype=torch.int32)
+    zq, codes = ops.fsq_encode(z.to(DEV), 4 * G, lens.to(DEV), k12, B=B, T=T, t_pad=t_pad, G=G, levels=levels)
+    zz = z.view(B, T, G, 4)
+    comp = scale * torch.tanh(zz + shift) - offset
+    # elements within 1e-6 of a rounding boundary may differ by a tanh ulp (f32 tanh here, double in the kernel): none may decide
+    assert ((comp - comp.floor() - 0.5).abs() > 1e-5).all()
+    c = torch.round(comp)
+    mask = torch.arange(T)[None, :] < lens[:, None]
+    want_zq = (c / half) * mask[:, :, None, None]
+    want_idx = (((c + half) * base.float()).sum(-1).to(torch.int32)) * mask[:, :, None]
+    assert torch.equal(codes[:, :, :T].cpu(), want_idx.permute(2, 0, 1))
+    assert torch.equal(zq[:, :T].cpu(), want_zq.reshape(B, T, 4 * G))
+    assert (codes[:, :, T:] == 0).all() and (zq[:, T:] == 0).all()
+    # every code of the codebook
+    n = int(torch.prod(lv))
+    allc = torch.arange(n, dtype=torch.int64).view(1, 1, n).expand(G, 1, n).contiguous()
+    dq = ops.fsq_decode(allc.to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV), B=1, T=n, G=G, levels=levels).cpu()
+    idx = torch.arange(n)
+    for d in range(4):
+        want = (((idx // base[d]) % lv[d]) - lv[d] // 2).float() / (lv[d] // 2)
+        assert torch.equal(dq[0, :, d], want) and torch.equal(dq[0, :, 4 * (G - 1) + d], want)
+    with pytest.raises(Exception):
+        ops.fsq_decode(allc.to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV), B=1, T=n, G=G, levels=(8, 7, 6, 1))
