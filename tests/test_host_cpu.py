@@ -306,3 +306,25 @@ def test_pcm16_fast_path_files_equal_the_float_path(tmp_path):
     assert wavio.read_pcm16(str(tmp_path / "c.wav"), 16000) is None
     (tmp_path / "d.flac").write_bytes(b"fLaC")
     assert wavio.read_pcm16(str(tmp_path / "d.flac"), 16000) is None
+
+
+def test_build_options_still_compile(tmp_path):
+    """The kernels kept as build options (measured, parity-tested on the GPU when they were built, not the default) must keep
+    compiling: -DCX_MFMA16=1 (ConvNeXt block on 16 x 16 x 32 MFMAs, profiles/r03_convnext_mfma16.txt) and the timing-ablation
+    builds of the attention kernel (-DATT_ABL, profiles/r03_attention_ablation.txt).  Cross-compiles for gfx950, no GPU needed."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "simwhisper_codec_amd", "csrc")
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-fno-slp-vectorize",
+              "-I", os.path.join(root, "include"), "-I", csrc, "-c"]
+    jobs = [(["-DCX_MFMA16=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], "swc_convnext.hip"),
+            (["-DATT_ABL=62"], "swc_attention16.hip")]
+    procs = [subprocess.Popen(common + flags + [os.path.join(csrc, src), "-o", str(tmp_path / (src + ".o"))],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for flags, src in jobs]
+    for (flags, src), p in zip(jobs, procs):
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, f"{src} {flags}:\n{out[-2000:]}"
