@@ -120,32 +120,53 @@ class HostStager:
         return [dev[o:o + n] for o, n in zip(offs, lens)]
 
     @staticmethod
+    def _by_buffer(tensors):
+        """tensors grouped by the buffer they are views of: [(base or None, [indices])].  decode() returns rows of ONE padded
+        buffer, DataParallelCodec.encode_decode rows of one buffer per rank: a few groups, not one per utterance."""
+        groups, where = [], {}
+        for i, t in enumerate(tensors):
+            b = t._base
+            ok = b is not None and b.device.type == "cuda" and b.is_contiguous()
+            k = id(b) if ok else ("single", i)
+            if k not in where:
+                where[k] = len(groups)
+                groups.append((b if ok else None, []))
+            groups[where[k]][1].append(i)
+        return groups
+
+    @staticmethod
     def pcm16_on_device(tensors):
-        """f32 device tensors (decode()'s rows of one padded buffer) -> int16 device tensors round(clip(x, -1, 1) * 32767), again
-        rows of ONE buffer (swc_f32_to_pcm16 over the padded buffer; launched on the current stream, nothing is copied).
-        to_host() then moves half the bytes in one copy; the samples are those wavio.save_audio writes, bit for bit."""
+        """f32 device tensors (decode()'s rows of a padded buffer) -> int16 device tensors round(clip(x, -1, 1) * 32767), again
+        rows of one buffer per source buffer (swc_f32_to_pcm16 over the whole padded buffer; launched on the current stream,
+        nothing is copied).  to_host() then moves half the bytes in one copy per buffer; the samples are those
+        wavio.save_audio writes, bit for bit."""
         from . import ops
-        if not tensors:
-            return []
-        base = tensors[0]._base
-        if (base is None or base.device.type != "cuda" or not base.is_contiguous() or base.dtype != torch.float32
-                or any(t._base is not base for t in tensors)):
-            out = []
-            for t in tensors:
-                with torch.cuda.device(t.device):
-                    out.append(ops.f32_to_pcm16(t.contiguous()))
-            return out
-        with torch.cuda.device(base.device):
-            b16 = ops.f32_to_pcm16(base)
-        return [b16.as_strided(t.size(), t.stride(), t.storage_offset() - base.storage_offset()) for t in tensors]
+        out = [None] * len(tensors)
+        for base, idx in HostStager._by_buffer(tensors):
+            if base is None or base.dtype != torch.float32:
+                for i in idx:
+                    with torch.cuda.device(tensors[i].device):
+                        out[i] = ops.f32_to_pcm16(tensors[i].contiguous())
+                continue
+            with torch.cuda.device(base.device):
+                b16 = ops.f32_to_pcm16(base)
+            for i in idx:
+                t = tensors[i]
+                out[i] = b16.as_strided(t.size(), t.stride(), t.storage_offset() - base.storage_offset())
+        return out
 
     @staticmethod
     def to_host(tensors):
-        if not tensors:
-            return []
-        base = tensors[0]._base
-        if (base is None or base.device.type != "cuda" or not base.is_contiguous()
-                or any(t._base is not base for t in tensors)):
-            return [t.cpu() for t in tensors]
-        host = base.cpu()  # (a copy on the current stream: the producing stream must have been synchronised or be this one)
-        return [host.as_strided(t.size(), t.stride(), t.storage_offset() - base.storage_offset()) for t in tensors]
+        """device tensors -> host tensors, one copy per source buffer (see _by_buffer) instead of one per utterance.  The copies
+        run on the current stream: the producing stream must have been synchronised, or be this one."""
+        out = [None] * len(tensors)
+        for base, idx in HostStager._by_buffer(tensors):
+            if base is None:
+                for i in idx:
+                    out[i] = tensors[i].cpu()
+                continue
+            host = base.cpu()
+            for i in idx:
+                t = tensors[i]
+                out[i] = host.as_strided(t.size(), t.stride(), t.storage_offset() - base.storage_offset())
+        return out

@@ -93,6 +93,13 @@ def test_host_stager_moves_the_same_values_as_the_per_file_path(tmp_path):
     for r, h in zip(rows, host):
         want = torch.from_numpy(np.round(np.clip(r.cpu().numpy(), -1.0, 1.0) * 32767.0).astype("<i2"))
         assert h.dtype == torch.int16 and torch.equal(h, want)
+    # rows of two buffers (what rank 0 of DataParallelCodec gets: one buffer per rank), interleaved: one conversion and copy each
+    base2 = torch.randn(3, 700, device=dev)
+    mixed = [base[0, :100], base2[1, :700], base[3, :9], base2[0, :1]]
+    d16 = st.pcm16_on_device(mixed)
+    assert d16[0]._base is d16[2]._base and d16[1]._base is d16[3]._base and d16[0]._base is not d16[1]._base
+    for r, h in zip(mixed, st.to_host(d16)):
+        assert torch.equal(h, torch.from_numpy(np.round(np.clip(r.cpu().numpy(), -1.0, 1.0) * 32767.0).astype("<i2")))
     # no common buffer: per-tensor fall-back, same values
     loose = [torch.randn(100, device=dev), torch.randn(7, device=dev)]
     for r, h in zip(loose, st.to_host(st.pcm16_on_device(loose))):
