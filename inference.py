@@ -23,6 +23,7 @@ import argparse
 import logging
 import os
 import sys
+import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -121,20 +122,25 @@ def main(argv=None):
     # wall seconds per stage, summed over the threads that run them (they overlap).  The launch threads (process) do nothing but
     # launch: reading + staging runs in the loader thread, the device -> host copy + writing in the saver thread
     spent = {"load+h2d": 0.0, "encode+decode": 0.0, "d2h+save": 0.0}
+    spent_lock = threading.Lock()
+
+    def account(stage, seconds):
+        with spent_lock:
+            spent[stage] += seconds
 
     def load(paths):
         t = time.perf_counter()
         wavs = stage_in(list(io.map(load_one, paths)))
         if on_gpu:
             torch.cuda.current_stream(device).synchronize()   # the staging buffer is re-used by the next batch
-        spent["load+h2d"] += time.perf_counter() - t
+        account("load+h2d", time.perf_counter() - t)
         return wavs
 
     def save(paths, wavs):
         t = time.perf_counter()
         host = stager.to_host(wavs) if on_gpu else wavs        # (the batch's stream was synchronised before it was handed back)
         list(io.map(save_one, zip(paths, host)))
-        spent["d2h+save"] += time.perf_counter() - t
+        account("d2h+save", time.perf_counter() - t)
 
     def process(model, item):
         """one batch on `model` (the generator or its replica), on the calling thread's stream"""
@@ -146,7 +152,7 @@ def main(argv=None):
             out = stager.pcm16_on_device(syn) if on_gpu else [w.cpu() for w in syn]
             if on_gpu:
                 torch.cuda.current_stream().synchronize()
-            spent["encode+decode"] += time.perf_counter() - t1
+            account("encode+decode", time.perf_counter() - t1)
             return paths, [c.shape[-1] for c in codes_list], out
 
     pipe = None
