@@ -8,18 +8,23 @@ import numpy as np, torch
 from simwhisper_codec_amd import ops, _lib
 
 SHAPES = {"qkv": (16000, 2304, 768, 0, 1), "out_proj": (16000, 768, 768, 0, 0), "fc1": (16000, 3072, 768, 1, 1),
-          "fc2": (16000, 768, 3072, 0, 0), "pw1": (32000, 4096, 512, 1, 1), "pw2": (32000, 512, 4096, 0, 0)}
+          "fc2": (16000, 768, 3072, 0, 0), "pw1": (32000, 4096, 512, 1, 1), "pw2": (32000, 512, 4096, 0, 0),
+          # the k7 convolutions of the samplers at the metric's batch, as a plain GEMM of the same M, N and K (4-wave 64 x 128 tiles)
+          "samp_k7": (4000, 512, 3584, 0, 0)}
 
 def main():
     lib = _lib.load()
     fn = lib.swc_debug_stamps
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int]; fn.restype = ctypes.c_int
     buf = np.zeros(512 * 8 * 8, dtype=np.uint64)
-    kinds = [a for a in sys.argv[1:] if not a.startswith("M=")] or ["bf16", "f16s"]
+    only = [a[5:] for a in sys.argv[1:] if a.startswith("only=")]
+    kinds = [a for a in sys.argv[1:] if not a.startswith(("M=", "only="))] or ["bf16", "f16s"]
     mscale = [float(a[2:]) for a in sys.argv[1:] if a.startswith("M=")] or [1.0]   # M=0.25: a quarter of the rows (fewer workgroups)
     for kind in kinds:
       for ms in mscale:
         for name, (M, N, K, gelu, obf) in SHAPES.items():
+            if only and name not in only:
+                continue
             M = int(M * ms)
             dev = "cuda"
             if kind == "f16s":
