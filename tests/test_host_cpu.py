@@ -278,6 +278,13 @@ def test_wav_reader_against_the_reference_assets():
         assert zlib.crc32(pcm.tobytes()) & 0xFFFFFFFF == r["crc32_pcm"], name
         y = wavio.load_audio(os.path.join(ref_dir, name), 16000)   # the CLI's loader: mono, 16 kHz
         assert y.reshape(-1).shape[0] == -(-r["frames"] * 16000 // r["rate"])
+        # the CLI's 16-bit fast path takes exactly the mono PCM16 files at the model's rate and returns their samples
+        fast = wavio.read_pcm16(os.path.join(ref_dir, name), 16000)
+        if r["rate"] == 16000 and r["channels"] == 1 and r.get("sample_width", 2) == 2:
+            assert fast is not None and zlib.crc32(fast.numpy().astype("<i2").tobytes()) & 0xFFFFFFFF == r["crc32_pcm"], name
+            assert torch.equal(fast.to(torch.float32) / 32768.0, y.reshape(-1))
+        else:
+            assert fast is None, name
 
 
 def test_pcm16_fast_path_files_equal_the_float_path(tmp_path):
