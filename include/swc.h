@@ -197,6 +197,27 @@ int swc_convnext_block(const float* x, float* x_out, const float* dw_w7, const f
                        void* stream);
 
 /*
+ * The MLP sub-block of one OmniWhisperTransformerLayer in one kernel (modules.py:224-232: final_layer_norm -> fc1 ->
+ * exact GELU -> fc2 -> + residual), 12x per encoder / decoder call:
+ *     x_out[M][D] = x + ( GELU( LayerNorm(x; ln_w, ln_b, eps) W1^T + b1 ) W2^T + b2 )
+ *     y_next[M][D] = LayerNorm(x_out; next_ln_w, next_ln_b, eps) in bf16      (optional: y_next == NULL skips it)
+ * x / x_out: f32 residual stream (x_out may be x: rows are independent); y_next is the operand of the NEXT layer's q/k/v
+ * projection (self_attn_layer_norm, modules.py:216), so neither LayerNorm of the layer is a launch of its own and the
+ * [M][F] hidden activations never exist in memory (two swc_gemm calls write and re-read them: 98 MB per layer at
+ * 32 x 10 s).  bf16 operands, f32 accumulation; GELU is the refit sigmoid form of the bf16 swc_gemm epilogue
+ * (|error| <= 2.7e-4).  Built for D = 768, F % 256 == 0 (the shipped 768 / 3072); other geometries return SWC_E_ARG and the
+ * caller runs swc_layernorm + two swc_gemm calls instead.  `w_stream` is the pair (fc1.weight [F][D], fc2.weight [D][F]) in
+ * bf16, re-ordered ONCE at load by swc_mlp_pack into the order in which each wave consumes 1 KiB MFMA operand fragments
+ * (swc_mlp_stream_bytes(D, F) bytes, 0 for an unsupported geometry).  Padded rows are computed like any other row, as in
+ * the reference (the layer masks keys, not rows: modules.py:169-177).
+ */
+int64_t swc_mlp_stream_bytes(int32_t D, int32_t F);
+int swc_mlp_pack(const void* w1_bf16, const void* w2_bf16, void* w_stream, int32_t D, int32_t F, void* stream);
+int swc_mlp_block(const float* x, float* x_out, const float* ln_w, const float* ln_b, float eps, const void* w_stream,
+                  const float* b1, const float* b2, const float* next_ln_w, const float* next_ln_b, void* y_next,
+                  int32_t M, int32_t D, int32_t F, void* stream);
+
+/*
  * ConvNeXt front half: depthwise Conv1d(k=7, pad=3, groups=C) + LayerNorm(eps)
  * (modules.py:1233-1239).  x: [B][T][C] f32, w: [7][C], y: [B][T][C] (y_dtype).
  */

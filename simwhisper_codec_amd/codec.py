@@ -91,7 +91,7 @@ def _register(root, name, tensor):
 
 
 class _Layer:
-    __slots__ = ("ln1", "wqkv", "bqkv", "wo", "bo", "ln2", "w1", "b1", "w2", "b2")
+    __slots__ = ("ln1", "wqkv", "bqkv", "wo", "bo", "ln2", "w1", "b1", "w2", "b2", "ws")  # ws: swc_mlp_block's operand stream (bf16)
 
 
 class _Packed:
@@ -442,7 +442,8 @@ class AudioCodec(nn.Module):
                        "pack the checkpoint again")
 
     _TUNABLES = ("saturation_policy", "varlen_packing", "length_bucketing", "bucket_overhead_tokens", "trim_vocos", "ragged_vocos",
-                 "vocos_streams", "vocos_phase_us", "vocos_split_override", "max_rows_per_call", "fused_mlp_min_rows")
+                 "vocos_streams", "vocos_phase_us", "vocos_split_override", "max_rows_per_call", "fused_mlp_min_rows",
+                 "fused_layer_mlp_min_rows")
 
     def replica(self):
         """A second AudioCodec over the SAME device-resident operands (nothing is copied or re-packed), with its own
@@ -526,6 +527,9 @@ class AudioCodec(nn.Module):
                 L.ln2 = (V(sd[p + "final_layer_norm.weight"]), V(sd[p + "final_layer_norm.bias"]))
                 L.w1, L.b1 = W(sd[p + "fc1.weight"], dt), V(sd[p + "fc1.bias"])
                 L.w2, L.b2 = W(sd[p + "fc2.weight"], dt), V(sd[p + "fc2.bias"])
+                # the fused MLP sub-block kernel (swc_mlp_block) exists for the shipped geometry with bf16 operands
+                L.ws = (ops.mlp_pack(L.w1.w, L.w2.w)
+                        if dt == torch.bfloat16 and ops.mlp_supported(L.w1.w.shape[1], L.w1.w.shape[0]) else None)
                 out.append(L)
             return out
 
@@ -651,24 +655,50 @@ class AudioCodec(nn.Module):
     def _transformer(self, h, lens, B, T, layers, H, dt, row_start=None):
         """12 x OmniWhisperTransformerLayer (modules.py:214-232). h: f32 residual stream (updated in place), padded
         [B*T, D] or — row_start given — packed [sum(len), D] (every row-wise kernel just sees fewer rows; attention finds
-        utterance b at row_start[b])."""
+        utterance b at row_start[b]).
+        bf16 operands at the shipped geometry: the MLP sub-block is ONE kernel (swc_mlp_block) that also applies the
+        LayerNorm in front of it and emits the normalised operand of the NEXT layer's q/k/v projection, so a layer is
+        qkv GEMM -> attention -> out-proj GEMM -> swc_mlp_block: no LayerNorm launch except the first of the stack."""
         D = h.shape[-1]
         M = h.shape[0]
         fp8 = dt == ops.FP8_T
         adt = torch.bfloat16 if fp8 else dt  # fp8 linears feed a bf16 attention
         lnB, lnT = (B, T) if row_start is None else (1, M)
-        for L in layers:
-            x = ops.layernorm(h, L.ln1[0], L.ln1[1], 1e-5, B=lnB, t_in=lnT, C_=D, out_dtype=dt)
+        fused = self._mlp_fused(layers, M, dt)
+        x = None  # the normalised operand of this layer's q/k/v projection when the previous layer's MLP kernel produced it
+        for i, L in enumerate(layers):
+            if x is None:
+                x = ops.layernorm(h, L.ln1[0], L.ln1[1], 1e-5, B=lnB, t_in=lnT, C_=D, out_dtype=dt)
             qkv = self._mm(x, L.wqkv, M, 3 * D, D, lda=D, bias=L.bqkv, out_dtype=adt)
             a = ops.attention(qkv, lens, B, T, H, row_start=row_start, rows=M)
             if fp8:
                 a = ops.cast_fp8(a)
             self._mm(a, L.wo, M, D, D, lda=D, bias=L.bo, residual=h, out=h)
-            x = ops.layernorm(h, L.ln2[0], L.ln2[1], 1e-5, B=lnB, t_in=lnT, C_=D, out_dtype=dt)
             F_ = L.b1.shape[0]
+            if fused:
+                nxt = layers[i + 1].ln1 if i + 1 < len(layers) else None
+                _, x = ops.mlp_block(h, L.ln2[0], L.ln2[1], 1e-5, L.ws, L.b1, L.b2, M=M, D=D, F=F_, next_ln=nxt)
+                continue
+            x = ops.layernorm(h, L.ln2[0], L.ln2[1], 1e-5, B=lnB, t_in=lnT, C_=D, out_dtype=dt)
             f = self._mm(x, L.w1, M, F_, D, lda=D, bias=L.b1, act=ops.ACT_GELU, out_dtype=dt)
             self._mm(f, L.w2, M, D, F_, lda=F_, bias=L.b2, residual=h, out=h)
+            x = None
         return h
+
+    # tokens from which the transformer's MLP sub-block runs as swc_mlp_block (64-token tiles, one per CU: below ~160 busy
+    # CUs the two-GEMM form, whose 64/128-row tiles of N = 3072 spread over more CUs, is faster)
+    fused_layer_mlp_min_rows = 64 * 160
+
+    def _mlp_fused(self, layers, M, dt):
+        if dt != torch.bfloat16 or M < self.fused_layer_mlp_min_rows:
+            return False
+        if any(getattr(L, "ws", None) is None for L in layers):
+            return False
+        if self.fused_layer_mlp_min_rows <= 0:  # forced (tests run the kernel on the few-second fixtures)
+            return True
+        tiles = spec.cdiv(M, 64)
+        rounds = spec.cdiv(tiles, self.CUS)
+        return tiles >= 0.6 * rounds * self.CUS  # a poorly filled last round of 64-token tiles costs a whole round
 
     conv1_split_f16 = True  # `mixed`: conv1 on the split-f16 MFMA path (mel bins padded 80 -> 96); False: exact f32 (read at pack time)
     varlen_packing = True   # ragged calls: the transformers run on the valid tokens only (packed rows), not on B x longest

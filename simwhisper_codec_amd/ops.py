@@ -364,6 +364,50 @@ def convnext_block(x, x_out, w7, dw_bias, ln_w, ln_b, eps, w_stream, b1, b2, gam
     return x_out
 
 
+def mlp_supported(D, F):
+    return _lib.load().swc_mlp_stream_bytes(D, F) > 0
+
+
+def mlp_pack(w1, w2):
+    """fc1.weight [F, D] and fc2.weight [D, F] (bf16, device) -> the packed operand stream of swc_mlp_block."""
+    lib = _lib.load()
+    _chk(w1, "mlp_pack w1", torch.bfloat16); _chk(w2, "mlp_pack w2", torch.bfloat16)
+    F_, D = w1.shape
+    if tuple(w2.shape) != (D, F_):
+        raise _lib.SwcError(f"mlp_pack: w2 is {tuple(w2.shape)}, expected {(D, F_)}")
+    n = lib.swc_mlp_stream_bytes(D, F_)
+    if n <= 0:
+        raise _lib.SwcError(f"mlp_pack: unsupported geometry D={D} F={F_}")
+    out = torch.empty(n, dtype=torch.uint8, device=w1.device)
+    _lib.check(lib.swc_mlp_pack(_ptr(w1.contiguous()), _ptr(w2.contiguous()), _ptr(out), D, F_, _stream()), "swc_mlp_pack")
+    return out
+
+
+def mlp_block(x, ln_w, ln_b, eps, w_stream, b1, b2, *, M, D, F, x_out=None, next_ln=None, y_next=None):
+    """One transformer MLP sub-block in one kernel (swc_mlp_block): x [M, D] f32 residual stream -> x_out (default: in place).
+    next_ln = (weight, bias) of the LayerNorm that follows (the next layer's self_attn_layer_norm): its bf16 output is
+    returned as the second value (None without next_ln)."""
+    lib = _lib.load()
+    _chk(x, "mlp_block x", torch.float32)
+    x_out = x if x_out is None else _chk(x_out, "mlp_block x_out", torch.float32)
+    nw = nb = None
+    if next_ln is not None:
+        nw, nb = next_ln
+        if y_next is None:
+            y_next = torch.empty((M, D), device=x.device, dtype=torch.bfloat16)
+        _chk(y_next, "mlp_block y_next", torch.bfloat16)
+    else:
+        y_next = None
+    prof = PROFILER
+    if prof is not None:
+        prof.begin("mlp_bf16", 4.0 * M * D * F)
+    _lib.check(lib.swc_mlp_block(_ptr(x), _ptr(x_out), _ptr(ln_w), _ptr(ln_b), eps, _ptr(w_stream), _ptr(b1), _ptr(b2), _ptr(nw),
+                                 _ptr(nb), _ptr(y_next), M, D, F, _stream()), "swc_mlp_block")
+    if prof is not None:
+        prof.end()
+    return x_out, y_next
+
+
 def delay_us(us):
     """occupy the current stream for `us` microseconds (phase shift between two streams)"""
     _lib.check(_lib.load().swc_delay_us(int(us), _stream()), "swc_delay_us")

@@ -830,3 +830,70 @@ def test_fsq_other_level_sets(levels):
         assert torch.equal(dq[0, :, d], want) and torch.equal(dq[0, :, 4 * (G - 1) + d], want)
     with pytest.raises(Exception):
         ops.fsq_decode(allc.to(DEV), torch.tensor([n], dtype=torch.int32, device=DEV), B=1, T=n, G=G, levels=(8, 7, 6, 1))
+
+
+@pytest.mark.parametrize("M,F_,with_next", [(64, 256, True), (300, 512, True), (77, 256, False), (1000, 3072, True),
+                                            (16000, 3072, True)])
+def test_mlp_block_fused(M, F_, with_next):
+    """swc_mlp_block (LayerNorm + fc1 + GELU + fc2 + residual + the NEXT LayerNorm in one kernel, modules.py:224-232,216) vs
+    (a) an f64 evaluation on the same bf16 weights and (b) the four launches it replaces (swc_layernorm, two swc_gemm,
+    swc_layernorm).  M covers partial 64-token tiles, F one to 12 hidden slices; in place."""
+    ops = _ops()
+    D = 768
+    g = torch.Generator().manual_seed(M * 3 + F_)
+    x0 = torch.randn(M, D, generator=g) * 1.5 + 0.1
+    lw, lb = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    nw, nb = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    w1 = (torch.randn(F_, D, generator=g) * D ** -0.5).to(torch.bfloat16)
+    w2 = (torch.randn(D, F_, generator=g) * F_ ** -0.5).to(torch.bfloat16)
+    b1, b2 = torch.randn(F_, generator=g) * 0.3, torch.randn(D, generator=g) * 0.3
+    d = lambda t: t.to(DEV)
+    ws = ops.mlp_pack(d(w1), d(w2))
+    x = d(x0).clone()
+    xo, yn = ops.mlp_block(x, d(lw), d(lb), 1e-5, ws, d(b1), d(b2), M=M, D=D, F=F_, next_ln=(d(nw), d(nb)) if with_next else None)
+    assert xo.data_ptr() == x.data_ptr() and torch.isfinite(xo).all()
+    # (b) the unfused launches on the same operands
+    y = ops.layernorm(d(x0), d(lw), d(lb), 1e-5, B=1, t_in=M, C_=D, out_dtype=torch.bfloat16)
+    hh = ops.gemm(y.view(M, D), d(w1), M, F_, D, bias=d(b1), act=ops.ACT_GELU, out_dtype=torch.bfloat16)
+    x2 = d(x0).clone()
+    ops.gemm(hh, d(w2), M, D, F_, bias=d(b2), residual=x2, out=x2)
+    # (a) f64 with y and h rounded to bf16 where the kernels round them
+    yr = F.layer_norm(x0.double(), (D,), lw.double(), lb.double(), 1e-5)
+    h = F.gelu(yr @ w1.double().T + b1.double())
+    ref = x0.double() + h @ w2.double().T + b2.double()
+    scale = float((ref - x0.double()).abs().max())
+    e_ref = float((xo.cpu().double() - ref).abs().max()) / scale
+    e_two = float((xo.cpu().double() - x2.cpu().double()).abs().max()) / scale
+    e_two_ref = float((x2.cpu().double() - ref).abs().max()) / scale
+    assert e_ref < 1e-2, (e_ref, e_two_ref)
+    assert e_ref < 2.0 * e_two_ref + 1e-4, (e_ref, e_two_ref)
+    assert e_two < 5e-3, e_two
+    if with_next:
+        assert yn.shape == (M, D) and yn.dtype == torch.bfloat16
+        # LayerNorm_next of the kernel's own x_out: the arithmetic of swc_layernorm, bit for bit
+        want = ops.layernorm(xo, d(nw), d(nb), 1e-5, B=1, t_in=M, C_=D, out_dtype=torch.bfloat16).view(M, D)
+        assert torch.equal(yn, want)
+    else:
+        assert yn is None
+
+
+def test_mlp_block_out_of_place_and_errors():
+    ops = _ops()
+    from simwhisper_codec_amd._lib import SwcError
+    D, F_, M = 768, 256, 130
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(M, D, generator=g).to(DEV)
+    one, zero = torch.ones(D, device=DEV), torch.zeros(D, device=DEV)
+    w1 = (torch.randn(F_, D, generator=g) * D ** -0.5).to(torch.bfloat16).to(DEV)
+    w2 = (torch.randn(D, F_, generator=g) * F_ ** -0.5).to(torch.bfloat16).to(DEV)
+    ws = ops.mlp_pack(w1, w2)
+    b1, b2 = torch.zeros(F_, device=DEV), torch.zeros(D, device=DEV)
+    a = x0.clone()
+    ops.mlp_block(a, one, zero, 1e-5, ws, b1, b2, M=M, D=D, F=F_)
+    out = torch.full_like(x0, float("nan"))
+    keep = x0.clone()
+    ops.mlp_block(x0, one, zero, 1e-5, ws, b1, b2, M=M, D=D, F=F_, x_out=out)
+    assert torch.equal(x0, keep) and torch.equal(out, a)
+    assert not ops.mlp_supported(512, 2048) and not ops.mlp_supported(768, 3000) and ops.mlp_supported(768, 3072)
+    with pytest.raises(SwcError):
+        ops.mlp_pack(w1[:, :512].contiguous(), w2[:512].contiguous())
