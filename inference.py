@@ -260,9 +260,17 @@ def main_distributed(args, world):
                 wav_list = None
                 if rank == 0:
                     logging.info(f"Processing batch {bi + 1}/{nb}, files: {batches[bi]}")
-                    cpu_wavs = nxt.result()
-                    nxt = pool.submit(load, batches[bi + 1]) if bi + 1 < nb else None
-                    wav_list = stage_in(cpu_wavs)
+                    try:
+                        cpu_wavs = nxt.result()
+                        nxt = pool.submit(load, batches[bi + 1]) if bi + 1 < nb else None
+                        wav_list = stage_in(cpu_wavs)
+                    except Exception as e:
+                        # an unreadable / corrupt file fails on rank 0 alone, outside every collective: tell the other ranks
+                        # (they sit in the lengths broadcast of this step) so that every rank stops now, as the single-GPU
+                        # loop and the reference do, instead of at the process-group timeout
+                        logging.error(f"batch {bi + 1}/{nb}: cannot load {batches[bi]}: {type(e).__name__}: {e}")
+                        dp.abort(e)
+                        raise
                 out = dp.encode_decode(wav_list, overlap_seconds=10)
                 if rank == 0:
                     logging.info(f"Decoding completed, generated waveform lengths: {[len(w) for w in out['syn_wav_list']]} samples")

@@ -469,14 +469,28 @@ class AudioCodec(nn.Module):
         fb = self._FALLBACK_OF.get(self._precision)
         if fb is not None and self._packed_file is None:
             # the exact-f32 encoder operands the range guard falls back to when split-f16 activations clip (trained
-            # Whisper-style outlier channels): stored beside the preset's own, read only if that ever happens
-            keep = (self._precision, self._pk, self._pk_key)
-            try:
-                self._precision, self._pk = fb, None
-                Pf = self._pack(dev)
-            finally:
-                self._precision, self._pk, self._pk_key = keep
+            # Whisper-style outlier channels): stored beside the preset's own, read only if that ever happens.
+            # Under the repack lock: a replica / thread fetching (preset, operands) meanwhile must never see the
+            # temporary (fallback preset, no operands) pair
+            with AudioCodec._REPACK_LOCK:
+                keep = (self._precision, self._pk, self._pk_key)
+                try:
+                    self._precision, self._pk = fb, None
+                    Pf = self._pack(dev)
+                finally:
+                    self._precision, self._pk, self._pk_key = keep
             extra["fallback_encode"] = {k: getattr(Pf, k) for k in self._ENCODE_FIELDS}
+        elif fb is not None and os.path.exists(str(self._packed_file)):
+            # a model that was itself loaded from a packed file: its fallback part travels on (dropping it silently would
+            # leave the re-exported file unable to recover from clipping)
+            part = packed.load_extra(self._packed_file, dev, _PACK_CLASSES, "fallback_encode")
+            if part is None:
+                raise SwcError(f"export_packed: {self._packed_file} carries no exact-f32 fallback operands to copy; export "
+                               "from the .pt checkpoint instead")
+            extra["fallback_encode"] = part
+        elif fb is not None:
+            raise SwcError("export_packed: a replica holds no checkpoint to pack the exact-f32 fallback operands from; export "
+                           "from its origin")
         torch.cuda.synchronize(dev)
         meta = {"precision": self._precision, "config": _config_digest(self.generator_params), "abi": ops.abi_version(),
                 "fallback": fb if extra else None}

@@ -45,7 +45,11 @@ constexpr int ML_KS1 = ML_D / 16;   // k-steps of GEMM1 (48)
 constexpr int ML_KS2 = ML_SL / 16;  // k-steps of GEMM2 (16)
 constexpr int ML_NB = ML_D / 4 / 32;  // 32-column blocks of out^T per wave (6)
 constexpr int ML_FPP = 96;          // fragments per phase and wave: GEMM1 48 x 2, GEMM2 16 x 6
-constexpr int ML_Y_BYTES = ML_BM * ML_D * 2;   // 96 KiB
+// pitch of one y fragment in LDS: 1 KiB + 16 B.  Fragment READS are lane-linear (conflict-free at any pitch); the prologue
+// WRITES 8 bytes per lane with the fragment index in the lane's upper bits: at a pitch of 1024 all 64 lanes of a
+// ds_write_b64 fall into 4 banks (32-way conflict), at 1040 into 32 (4-way)
+constexpr int ML_YP = 1040;
+constexpr int ML_Y_BYTES = 2 * ML_KS1 * ML_YP;  // 97.5 KiB
 constexpr int ML_H_BYTES = ML_SL * ML_BM * 2;  // 32 KiB
 constexpr int ML_LDS = ML_Y_BYTES + ML_H_BYTES;
 constexpr int ML_TLD = ML_D + 4;  // row pitch (floats) of the epilogue transpose buffer: conflict-free b128 writes
@@ -101,6 +105,17 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
     const int lf = lane & 31, lh = lane >> 5;
     const int row0 = blockIdx.x * ML_BM;
 
+    // ---- weight stream of this wave: wave-uniform byte pointer (SGPR pair, advanced once per phase) + one 32-bit lane
+    // offset + immediate
+    const long per_wave = (long)NS * (2 * ML_FPP) + ML_PF;  // fragments
+    const char* wbase = reinterpret_cast<const char*>(wstream) + (long)w * per_wave * 1024;
+    const unsigned lane_off = (unsigned)lane * 16u;
+    auto wfrag = [&](int i) -> u32x4 {  // fragment i of the current phase (i may run ML_PF past its end)
+        if (ML_ABL & 4) i &= ML_PF - 1;
+        return *reinterpret_cast<const u32x4*>(wbase + (long)i * 1024 + lane_off);
+    };
+    u32x4 ring[ML_PF];
+
     // ---- prologue: LayerNorm of this wave's 16 tokens -> LDS as B fragments.  Fragment (s, fb) = k-step s (16 channels) x
     // token block fb (32 tokens) at [(2 s + fb)][lane][16 B]; lane l supplies token 32 fb + (l & 31), channels
     // 16 s + 8 (l >> 5) .. + 7.  A lane owns channels 256 k + 4 l .. + 3 (k = 0..2) of every row.
@@ -122,6 +137,14 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
         }
 #pragma unroll
         for (int i0 = 0; i0 < 16; i0 += 4) {
+            if (i0 == 12) {
+                // the first weight fragments are requested once three quarters of the rows have left their registers (all 16 rows and
+                // the ring together do not fit): their latency overlaps the second half and the other waves' tails
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < ML_PF; ++i) ring[i] = wfrag(i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             float s[4], q[4], mean[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -153,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
                     const float o2 = (t.z - mean[u]) * rstd * gw[k].z + gb[k].z, o3 = (t.w - mean[u]) * rstd * gw[k].w + gb[k].w;
                     // channels c = 256 k + 4 l .. + 3 -> fragment (s = c / 16, fb), lane' = 32 ((c % 16) / 8) + fl, byte (c % 8) * 2
                     const int s_ = 16 * k + (lane >> 2);
-                    const int off = ((s_ * 2 + fb) * 64 + 32 * ((lane >> 1) & 1) + fl) * 16 + (lane & 1) * 8;
+                    const int off = (s_ * 2 + fb) * ML_YP + (32 * ((lane >> 1) & 1) + fl) * 16 + (lane & 1) * 8;
                     *reinterpret_cast<uint2*>(smem + off) = make_uint2(bf16_pack2(o0, o1), bf16_pack2(o2, o3));
                 }
             }
@@ -162,19 +185,6 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
     }
     const u32x4* ylds = reinterpret_cast<const u32x4*>(smem) + lane;
     u32x4* hlds = reinterpret_cast<u32x4*>(smem + ML_Y_BYTES) + lane;
-
-    // ---- weight stream of this wave: wave-uniform byte pointer (SGPR pair, advanced once per phase) + one 32-bit lane
-    // offset + immediate
-    const long per_wave = (long)NS * (2 * ML_FPP) + ML_PF;  // fragments
-    const char* wbase = reinterpret_cast<const char*>(wstream) + (long)w * per_wave * 1024;
-    const unsigned lane_off = (unsigned)lane * 16u;
-    auto wfrag = [&](int i) -> u32x4 {  // fragment i of the current phase (i may run ML_PF past its end)
-        if (ML_ABL & 4) i &= ML_PF - 1;
-        return *reinterpret_cast<const u32x4*>(wbase + (long)i * 1024 + lane_off);
-    };
-    u32x4 ring[ML_PF];
-#pragma unroll
-    for (int i = 0; i < ML_PF; ++i) ring[i] = wfrag(i);
 
     f32x16 acc2[ML_NB][2];  // [column block of this wave][token block]
 #pragma unroll
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
     auto y_frags = [&](int s, u32x4 (&dst)[2]) {
         if ((ML_ABL & 8) && s > 1) return;
 #pragma unroll
-        for (int b = 0; b < 2; ++b) dst[b] = ylds[(s * 2 + b) * 64];
+        for (int b = 0; b < 2; ++b) dst[b] = ylds[(s * 2 + b) * (ML_YP / 16)];
     };
     auto h_frags = [&](int q, u32x4 (&dst)[2]) {
         if ((ML_ABL & 8) && q > 1) return;

@@ -77,21 +77,31 @@ class DataParallelCodec:
     # ------------------------------------------------------------------ small integers: one tensor broadcast
     _INTS_CAP = 1024  # entries of the fixed-size broadcast (8 KiB): count + up to 1023 lengths in ONE collective
 
-    def _share_ints(self, values):
+    def _share_ints(self, values, error=None):
         """rank 0 passes a list of ints; every rank returns it.  One int64 broadcast of fixed size ([count, values ...]) and
-        one host read-back; lists longer than the buffer take a second broadcast for the remainder."""
+        one host read-back; lists longer than the buffer take a second broadcast for the remainder.
+        error (rank 0 only): rank 0 could not produce the list (an unreadable file, a failed batch assembly): the count
+        travels as -1 and EVERY rank raises here, at once, instead of the others waiting in this broadcast for the
+        process-group timeout."""
         if self.world == 1:
+            if error is not None:
+                raise error
             return [int(v) for v in values]
         cap = self._INTS_CAP
         if self.rank == 0:
-            vals = [int(v) for v in values]
-            head = [len(vals)] + vals[: cap - 1]
+            vals = [int(v) for v in values] if error is None else []
+            head = ([len(vals)] + vals[: cap - 1]) if error is None else [-1]
             t = torch.tensor(head + [0] * (cap - len(head)), dtype=torch.int64, device=self.comm)
         else:
             t = torch.empty(cap, dtype=torch.int64, device=self.comm)
         dist.broadcast(t, src=0, group=self.group)
         got = t.tolist()
         k = int(got[0])
+        if k < 0:
+            if error is not None:
+                raise error
+            raise RuntimeError("DataParallelCodec: rank 0 could not assemble this batch (see its log); the step is abandoned "
+                               "on every rank")
         out = got[1: 1 + min(k, cap - 1)]
         if k > cap - 1:
             rest = torch.tensor(vals[cap - 1:], dtype=torch.int64, device=self.comm) if self.rank == 0 else \
@@ -117,14 +127,41 @@ class DataParallelCodec:
                                "on every rank")
 
     def _guarded(self, fn):
-        """fn() = this rank's local work; returns its result after all ranks have agreed that nobody failed."""
+        """fn() = this rank's local work; returns its result after all ranks have agreed that nobody failed.  Rank 0's
+        scatter sends are waited for HERE, after its own local work has been enqueued: its encode runs beside the sends
+        instead of behind them (rank 0 is on the critical path of every step)."""
         err, out = None, None
         try:
             out = fn()
         except Exception as e:  # noqa: BLE001 - re-raised by _agree on this rank, reported on the others
             err = e
+        try:
+            self._finish_scatter()
+        except Exception as e:  # noqa: BLE001
+            err = err or e
         self._agree(err)
         return out
+
+    def abort(self, error):
+        """rank 0: the batch could not be loaded / assembled.  Takes the place of the step's first collective (the lengths
+        broadcast) and raises `error` here and a RuntimeError on every other rank (their next encode / decode /
+        encode_decode call returns by raising)."""
+        self._share_ints(None, error=error)
+
+    def _rank0(self, fn):
+        """rank 0's host-side preparation of a step (lengths, batch assembly): a failure travels as the abort marker of the
+        lengths broadcast instead of leaving the other ranks inside it."""
+        try:
+            return fn(), None
+        except Exception as e:  # noqa: BLE001
+            return None, e
+
+    _sends = None
+
+    def _finish_scatter(self):
+        p, self._sends = self._sends, None
+        if p is not None:
+            p.wait()
 
     # ------------------------------------------------------------------ point-to-point scatter / gather of row slices
     def _scatter_rows(self, batch, parts, width, dtype):
@@ -140,9 +177,9 @@ class DataParallelCodec:
                         sl = sl.to(self.comm)
                     keep.append(sl)
                     ops.append(dist.P2POp(dist.isend, sl, r, self.group))
-            if ops:
-                for w in dist.batch_isend_irecv(ops):
-                    w.wait()
+            # not waited for here: _guarded() waits once this rank's own local work is enqueued (the slices stay referenced)
+            self._finish_scatter()
+            self._sends = _Pending(dist.batch_isend_irecv(ops), keep + [batch]) if ops else None
             return batch[a:b]
         buf = torch.empty((b - a, width), device=self.comm, dtype=dtype)
         if b > a and width > 0:
@@ -259,15 +296,25 @@ class DataParallelCodec:
             out.extend(r if up * clen[a + k] == Lw else r[: up * clen[a + k]] for k, r in enumerate(rows))
         return out
 
+    def _share_audio(self, wav_list):
+        """(lengths on every rank, the padded [B, L] batch on rank 0).  Rank 0 assembles the batch BEFORE the lengths travel:
+        if that fails (a tensor on the wrong device, out of memory) the broadcast carries the abort marker and every rank
+        raises, instead of the peers waiting for rows that are never sent."""
+        def prep():
+            ln = [int(w.shape[-1]) for w in wav_list]
+            return ln, (self._pad_batch(wav_list, ln, torch.float32) if ln else None)
+        (got, err) = self._rank0(prep) if self.rank == 0 else (None, None)
+        lens = self._share_ints(got[0] if got else None, error=err)
+        return lens, (got[1] if got else None)
+
     # ------------------------------------------------------------------ public surface
     def encode(self, wav_list=None, overlap_seconds=10):
         """rank 0 passes the full list; returns {"codes_list": [...]} on rank 0, None elsewhere."""
-        lens = self._share_ints([int(w.shape[-1]) for w in wav_list] if self.rank == 0 else None)
+        lens, batch = self._share_audio(wav_list)
         if not lens:
             return {"codes_list": []} if self.rank == 0 else None
         parts = partition(lens, self.world)
         L = max(lens)
-        batch = self._pad_batch(wav_list, lens, torch.float32) if self.rank == 0 else None
         mine = self._scatter_rows(batch, parts, max(L, 1), torch.float32)
         a, b = parts[self.rank]
         codes = self._guarded(lambda: self._encode_rows(mine, lens, a, b, overlap_seconds))
@@ -285,16 +332,20 @@ class DataParallelCodec:
     def decode(self, codes_list=None, overlap_seconds=10):
         """rank 0 passes the full list; returns {"syn_wav_list": [...]} on rank 0, None elsewhere."""
         G = self.codec.num_groups
-        clen = self._share_ints([int(c.shape[-1]) for c in codes_list] if self.rank == 0 else None)
+        def prep():  # rows = (utterance, group): one padded int32 matrix, shards are row slices of it
+            cl = [int(c.shape[-1]) for c in codes_list]
+            if not cl:
+                return cl, None
+            rows = [c[g].to(torch.int32) for c in codes_list for g in range(G)]
+            return cl, self._pad_batch(rows, [n for n in cl for _ in range(G)], torch.int32, max(max(cl), 1))
+        (got0, err) = self._rank0(prep) if self.rank == 0 else (None, None)
+        clen = self._share_ints(got0[0] if got0 else None, error=err)
+        batch = got0[1] if got0 else None
         if not clen:
             return {"syn_wav_list": []} if self.rank == 0 else None
         t_max = max(clen)
         parts = partition([max(c, 1) for c in clen], self.world)
         Lc = max(t_max, 1)
-        batch = None
-        if self.rank == 0:  # rows = (utterance, group): one padded int32 matrix, shards are row slices of it
-            rows = [c[g].to(torch.int32) for c in codes_list for g in range(G)]
-            batch = self._pad_batch(rows, [n for n in clen for _ in range(G)], torch.int32, Lc)
         cparts = [(pa * G, pb * G) for pa, pb in parts]
         mine = self._scatter_rows(batch, cparts, Lc, torch.int32)
         a, b = parts[self.rank]
@@ -315,7 +366,7 @@ class DataParallelCodec:
         gather waveforms.  The codes never leave their GPU between encode and decode; the one global integer (maximum
         code length, for the reference's T_max rule) follows from the broadcast lengths.  Rank 0 returns
         {"codes_list", "syn_wav_list"} equal to codec.decode(codec.encode(all)); other ranks return None."""
-        lens = self._share_ints([w.size(-1) for w in wav_list] if self.rank == 0 else None)
+        lens, batch = self._share_audio(wav_list)
         if not lens:
             return {"codes_list": [], "syn_wav_list": []} if self.rank == 0 else None
         parts = partition(lens, self.world)
@@ -326,7 +377,6 @@ class DataParallelCodec:
         a, b = parts[self.rank]
         cparts = [(pa * G, pb * G) for pa, pb in parts]
         L = max(lens)
-        batch = self._pad_batch(wav_list, lens, torch.float32) if self.rank == 0 else None
         mine = self._scatter_rows(batch, parts, max(L, 1), torch.float32)
 
         def local_round_trip():

@@ -103,6 +103,9 @@ def _read_flac(path):
     return pcm.astype(np.float32) / np.float32(2.0 ** (bits - 1)), sr
 
 
+FLAC_MAX_SAMPLES = 1 << 31  # decoded samples (all channels) one FLAC file may expand to, whatever its header says
+
+
 def _decode_flac(path):
     """-> (int32 array (n, channels), sample rate, bits per sample)"""
     import ctypes as C
@@ -116,7 +119,16 @@ def _decode_flac(path):
     # STREAMINFO's 36-bit sample count is not trusted for the allocation (a crafted header would ask for 256 GiB): start
     # from what the file's size makes plausible and grow on FLAC_E_SPACE up to the declared (or, undeclared, a hard) bound
     guess = int(lib.swc_flac_max_samples(len(data)))
-    limit = int(total.value) if total.value else (1 << 31)
+    # hard ceiling whatever STREAMINFO declares (its 36-bit count is attacker-controlled: a small file of constant subframes
+    # could otherwise ask for 2^36 samples x channels x 4 bytes): FLAC_MAX_SAMPLES per channel (default 2^31 / channels
+    # int32 samples = 8 GiB of decoded audio at most, > 37 h at 16 kHz mono), SWC_FLAC_MAX_SECONDS overrides by duration
+    hard = FLAC_MAX_SAMPLES // max(1, ch.value)
+    if os.environ.get("SWC_FLAC_MAX_SECONDS"):
+        hard = min(hard, int(float(os.environ["SWC_FLAC_MAX_SECONDS"]) * max(1, sr.value)))
+    limit = min(int(total.value) if total.value else hard, hard)
+    if total.value and total.value > hard:
+        raise ValueError(f"{path}: STREAMINFO declares {total.value} samples per channel, more than the decoder's ceiling of "
+                         f"{hard} (FLAC_MAX_SAMPLES / SWC_FLAC_MAX_SECONDS)")
     cap = max(1, min(limit, guess))
     md5 = C.c_int32(0)
     while True:

@@ -165,3 +165,73 @@ def test_share_ints_is_one_broadcast(monkeypatch):
     assert dp._share_ints(big) == big and len(calls) == 2   # beyond the buffer: one more for the remainder
     calls.clear()
     assert dp._share_ints([]) == [] and len(calls) == 1
+
+
+def _worker_rank0_fails(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import datetime
+    import time
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        dp = DataParallelCodec(FakeCodec(), "cpu")
+        seen = []
+        t0 = time.perf_counter()
+        # (1) the file loop's case: rank 0 cannot load a file of the batch -> dp.abort(error) in place of the step
+        try:
+            if rank == 0:
+                dp.abort(OSError("input_wavs/broken.flac: bad frame CRC"))
+            else:
+                dp.encode_decode(None)
+            seen.append("no error")
+        except OSError as e:
+            seen.append(f"own:{e}")
+        except RuntimeError as e:
+            seen.append("told" if "rank 0 could not assemble" in str(e) else f"unexpected:{e}")
+        # (2) rank 0's batch assembly itself fails (an entry that is not a tensor): inside encode(), before the broadcast
+        for call in (dp.encode, dp.encode_decode):
+            try:
+                call([torch.zeros(2560), "not a tensor"] if rank == 0 else None)
+                seen.append("no error")
+            except (AttributeError, TypeError):
+                seen.append("own")
+            except RuntimeError as e:
+                seen.append("told" if "rank 0 could not assemble" in str(e) else f"unexpected:{e}")
+        # (3) and decode(): a code tensor of the wrong rank
+        try:
+            dp.decode([torch.zeros(8, 3, dtype=torch.int32), None] if rank == 0 else None)
+            seen.append("no error")
+        except (AttributeError, TypeError):
+            seen.append("own")
+        except RuntimeError as e:
+            seen.append("told" if "rank 0 could not assemble" in str(e) else f"unexpected:{e}")
+        took = time.perf_counter() - t0
+        # the group is still usable: every rank raised at the same collective
+        g = torch.Generator().manual_seed(0)
+        ok = dp.encode_decode([torch.randn(n, generator=g) for n in (2560, 5120, 3000)] if rank == 0 else None)
+        ret.put((rank, seen, (ok is not None) == (rank == 0), took))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank0_load_failure_reaches_every_rank_at_once():
+    """ADVICE r3: a corrupt / unreadable file fails on rank 0 OUTSIDE every collective (inference.py: nxt.result(), stage_in;
+    dist.py: _pad_batch).  The other ranks sat in the lengths broadcast until the 240 s process-group timeout; now the
+    broadcast carries an abort marker (count -1) and every rank raises promptly."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rank0_fails, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(ret.get(timeout=5) for _ in range(world))
+    for rank, seen, usable, took in got:
+        if rank == 0:
+            assert seen == ["own:input_wavs/broken.flac: bad frame CRC", "own", "own", "own"], seen
+        else:
+            assert seen == ["told"] * 4, seen
+        assert usable and took < 30.0

@@ -233,10 +233,12 @@ def _worker_bookkeeping(port, ret):
         dist.destroy_process_group()
 
 
-def test_rank0_bookkeeping_of_256_utterances_is_under_a_millisecond():
+def test_rank0_bookkeeping_of_256_utterances_stays_small():
     """BASELINE.json configs[3] at the real shape (8 ranks x 32 utterances x 10 s): the host work rank 0 does per step
     around the collectives — lengths, partition, batch assembly (one gather kernel), per-utterance views of the gathered
-    codes and waveforms — must stay under 1 ms, or rank 0's Python becomes the scaling limit (7 GPUs idle meanwhile)."""
+    codes and waveforms — is measured (0.4 ms on the round-3 boxes; it was 1.9 ms with one copy per utterance) and written
+    to the report; the assertion is a generous 5 ms, a wall-clock bound on a shared box that only a structural regression
+    (a per-utterance copy loop, a stream sync per row) crosses — ADVICE r3: a 1 ms gate flakes under host load."""
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     p = ctx.Process(target=_worker_bookkeeping, args=(_free_port(), ret))
@@ -244,8 +246,9 @@ def test_rank0_bookkeeping_of_256_utterances_is_under_a_millisecond():
     p.join(300)
     assert p.exitcode == 0
     med = ret.get(timeout=5)
-    os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/parity_report.txt", "a") as f:
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "parity_report.txt"), "a") as f:
         f.write(f"dist/rank0_bookkeeping_256 median_ms={1e3 * med:.3f}\n")
-    assert med < 1e-3, f"rank-0 bookkeeping takes {1e3 * med:.2f} ms per step"
+    assert med < 5e-3, f"rank-0 bookkeeping takes {1e3 * med:.2f} ms per step"
 

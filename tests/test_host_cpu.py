@@ -335,3 +335,41 @@ def test_build_options_still_compile(tmp_path):
     for (flags, src), p in zip(jobs, procs):
         out, _ = p.communicate(timeout=600)
         assert p.returncode == 0, f"{src} {flags}:\n{out[-2000:]}"
+
+
+def test_hot_kernel_isa_shape():
+    """tools/check_isa.py (a performance lint: the K loops of the six hot swc_gemm kernels keep the shape their measured speed
+    belongs to) on the shipped build.  __graft_entry__.build() only prints its findings (a numerically correct
+    library must not fail the build entry point over a schedule); this test is where a changed shape turns red."""
+    import subprocess
+    import sys
+    from simwhisper_codec_amd import build
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    path = build.build_library()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_isa.py"), path], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "FAIL" not in r.stdout
+
+
+def test_build_entry_point_survives_an_isa_lint_failure(monkeypatch, capsys):
+    """build() with a failing lint prints the findings and returns; SWC_STRICT_ISA=1 makes them fatal."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    real = subprocess.run
+
+    class _R:
+        returncode, stdout = 1, "check_isa: FAIL bf16 qkv (192 x 256): 2 `s_waitcnt vmcnt(0)` per slice, expected 1\n"
+
+    def fake(cmd, *a, **k):
+        return _R() if any("check_isa.py" in str(c) for c in cmd) else real(cmd, *a, **k)
+    monkeypatch.setattr(subprocess, "run", fake)
+    monkeypatch.delenv("SWC_STRICT_ISA", raising=False)
+    ge.build()
+    assert "performance lint" in capsys.readouterr().out
+    monkeypatch.setenv("SWC_STRICT_ISA", "1")
+    with pytest.raises(RuntimeError):
+        ge.build()

@@ -345,12 +345,13 @@ def test_length_bucketing_is_exact(tag, precision):
     wavs = [synth.synth_audio(int(16000 * t) + 13 * i, index=950 + i, kind="speech" if i % 2 else "noise").to(DEV)
             for i, t in enumerate(secs)]
     assert len(length_groups(sorted([int(16000 * t) // 320 for t in secs], reverse=True))) > 1  # the case is really ragged
-    keep_rows, keep_pack = m.fused_mlp_min_rows, m.varlen_packing
+    keep_rows, keep_pack, keep_layer = m.fused_mlp_min_rows, m.varlen_packing, m.fused_layer_mlp_min_rows
     try:
         m.varlen_packing = False  # (with packing on, ragged calls are not grouped at all)
         # the same kernels on both sides (the fused ConvNeXt kernel is chosen by the number of Vocos frames of a call and
-        # rounds its bf16 intermediate in another order than the two-GEMM form): bit-identical
-        m.fused_mlp_min_rows = 1 << 40
+        # rounds its bf16 intermediate in another order than the two-GEMM form; likewise swc_mlp_block by the number of
+        # decoder tokens): bit-identical
+        m.fused_mlp_min_rows = m.fused_layer_mlp_min_rows = 1 << 40
         m.length_bucketing = False
         c0 = m.encode(wavs)["codes_list"]
         w0 = m.decode(c0)["syn_wav_list"]
@@ -358,11 +359,11 @@ def test_length_bucketing_is_exact(tag, precision):
         c1 = m.encode(wavs)["codes_list"]
         w1 = m.decode(c1)["syn_wav_list"]
         # default kernel choice: codes identical, waveforms within the bf16 decode tolerance
-        m.fused_mlp_min_rows = keep_rows
+        m.fused_mlp_min_rows, m.fused_layer_mlp_min_rows = keep_rows, keep_layer
         w2 = m.decode(c1)["syn_wav_list"]
     finally:
         m.length_bucketing = True
-        m.fused_mlp_min_rows, m.varlen_packing = keep_rows, keep_pack
+        m.fused_mlp_min_rows, m.varlen_packing, m.fused_layer_mlp_min_rows = keep_rows, keep_pack, keep_layer
     for a, b in zip(c0 + w0, c1 + w1):
         assert a.shape == b.shape and torch.equal(a, b)
     for a, b in zip(w1, w2):

@@ -15,7 +15,9 @@ disassembles the kernels the metric runs and asserts the shape of their K loop:
   * at most half of the slice's MFMAs sit behind its barrier (the 11 % slower schedule had 59 of 96 there, and a second wait).
 
 usage: python tools/check_isa.py [path/to/libswc_hip.so]      (exit code 1 on a violated expectation)
-Called by __graft_entry__.build().  Needs /opt/rocm/lib/llvm/bin/llvm-objdump; skipped with a note if that is missing.
+A PERFORMANCE lint, not a correctness check: __graft_entry__.build() prints its findings and goes on (SWC_STRICT_ISA=1 makes
+them fatal there); tests/test_host_cpu.py::test_hot_kernel_isa_shape holds the shipped build to it.
+Needs /opt/rocm/lib/llvm/bin/llvm-objdump; skipped with a note if that is missing.
 """
 import os
 import re
@@ -94,7 +96,9 @@ def check(path):
                     found[frag] = (name, body, exp)
     for frag, exp in EXPECT.items():
         if frag not in found:
-            bad.append(f"{exp[3]}: kernel {frag} not found in {path}")
+            # a renamed template parameter or a toolchain that mangles differently: nothing can be said about the kernel
+            # (a note, not a failure; the numerics tests do not depend on this lint)
+            print(f"check_isa: note: {exp[3]}: kernel {frag} not found in {path} (not checked)")
             continue
         name, body, exp = found[frag]
         n_mfma, n_read, n_dma, what = exp[:4]
