@@ -25,7 +25,8 @@ Rank 0 prints ONE JSON line, with
   cpu_baseline — the CPU oracle (oracle/ref_cpu.py, the reference's algorithm incl. its 30 s padding) timed on this
                  box's host cores on a bounded sample of the same workload (N = 1 only): B = 8 x 10 s (BASELINE.json
                  configs[1]'s shape, the first 8 draws of the same generator), 1 warm-up + 3 timed passes, median (~60 s), on
-                 every core visible to the process (`cores` = threads used, `cores_visible` = len(sched_getaffinity)).
+                 every core the process may use (`cores` = threads used = min(`cores_visible` = len(sched_getaffinity),
+                 `cpu_quota` = the cgroup's cpu.max)).
   parity       — the run checks its own answer: the codes of utterance 0 of the LAST timed step must equal the CPU oracle's
                  (at most 2 of 1000 may differ — the oracle's own thread-count sensitivity; the count is reported and has been 0
                  on every box) and its waveform must lie within the bf16-decode tolerance of the oracle's (N = 1, cpu baseline
@@ -148,6 +149,28 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_allotment():
+    """(logical CPUs in this process's affinity mask, CPUs the cgroup quota grants or None).  The one-GPU boxes of the pool
+    show all 256 logical CPUs of a 2 x 64-core EPYC in the mask and grant 16 through `cpu.max` (1600000 100000): threads
+    beyond the quota only add throttling, so the quota is the core count a baseline can use there."""
+    visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    return visible, quota
+
+
 def cpu_baseline(gp, sd, shapes, seconds, threads, timed=3):
     """oracle/ref_cpu.py on the host cores: per shape 1 warm-up + `timed` timed encode+decode passes, median."""
     from oracle.ref_cpu import Oracle
@@ -160,6 +183,7 @@ def cpu_baseline(gp, sd, shapes, seconds, threads, timed=3):
         wavs = bench_inputs(n_utt, int(seconds * 16000))
         times = []
         for it in range(1 + timed):
+            print(f"bench: cpu baseline B={n_utt} pass {it}/{timed} on {threads} threads ...", file=sys.stderr, flush=True)
             t0 = time.perf_counter()
             codes = ora.encode(wavs)["codes_list"]
             wav = ora.decode(codes)["syn_wav_list"]
@@ -344,13 +368,14 @@ def main():
     exact_codes = args.precision in ("fp32", "mixed", "mixed_f32")  # bf16 / fp8 encoders agree statistically only
     wav_tol = 5e-5 if args.precision == "fp32" else 5e-2         # tests/test_parity_gpu.py TOL_FP32 / TOL_BF16
     if world == 1 and rank == 0 and args.cpu_baseline != "off":
-        # every core this process may run on (SURVEY.md 8d / BASELINE.md 2: "N = physical cores; report N"): the one-GPU box
-        # grants 16 of the host's cores; --cpu-threads overrides (tools/cpu_threads.py sweeps it: profiles/r04_cpu_threads.txt)
-        visible = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        threads = args.cpu_threads or visible
+        # every core this process may USE (SURVEY.md 8d / BASELINE.md 2: "N = physical cores; report N"): the affinity mask
+        # capped by the cgroup's CPU quota (the one-GPU box: 256 logical CPUs visible, 16 granted).  --cpu-threads overrides;
+        # tools/cpu_threads.py sweeps the count (profiles/r04_cpu_threads.txt: more threads than the quota are slower)
+        visible, quota = cpu_allotment()
+        threads = args.cpu_threads or max(1, min(visible, int(quota) if quota else visible))
         shapes = {"sample": [min(8, args.batch)], "small": [min(2, args.batch)], "full": [8, 32]}[args.cpu_baseline]
         cpu_res, first = cpu_baseline(gp, sd, shapes, args.seconds, threads, timed=1 if args.cpu_baseline == "small" else 3)
-        cpu_res["cores_visible"] = visible
+        cpu_res["cores_visible"], cpu_res["cpu_quota"] = visible, quota
         expect = {"source": "oracle/ref_cpu.py (CPU, fp32)", "codes": first["codes"], "wav": first["wav"]}
     else:
         r0 = model.encode(mine[:1], overlap_seconds=10, device=dev)["codes_list"]

@@ -218,6 +218,26 @@ int swc_mlp_block(const float* x, float* x_out, const float* ln_w, const float* 
                   int32_t M, int32_t D, int32_t F, void* stream);
 
 /*
+ * Everything of one OmniWhisperTransformerLayer behind the attention (modules.py:219-232: out_proj -> + residual ->
+ * final_layer_norm -> fc1 -> GELU -> fc2 -> + residual) in one kernel, plus the NEXT layer's self_attn_layer_norm:
+ *     x'           = x + attn Wo^T + bo                      attn: [M][D] bf16, the attention output (swc_attention16)
+ *     x_out[M][D]  = x' + ( GELU( LayerNorm(x'; ln_w, ln_b, eps) W1^T + b1 ) W2^T + b2 )
+ *     y_next[M][D] = LayerNorm(x_out; next_ln_w, next_ln_b, eps) in bf16                       (optional, as swc_mlp_block)
+ * swc_mlp_block with the out-projection in front of it: the workgroup's 64-token tile of attn goes to LDS by DMA, x' is
+ * accumulated in the registers that afterwards accumulate fc2 — it never exists in memory, its LayerNorm is taken in the
+ * accumulator layout (row statistics exchanged between the 4 waves through LDS), and the MLP's residual add costs nothing.
+ * A decoder layer is then three launches: q/k/v GEMM, attention, this.  Same geometry limits, operand types and GELU as
+ * swc_mlp_block; `w_stream` comes from swc_layer_tail_pack(out_proj.weight [D][D], fc1.weight [F][D], fc2.weight [D][F])
+ * (swc_layer_tail_stream_bytes(D, F) bytes).  x_out may be x.
+ */
+int64_t swc_layer_tail_stream_bytes(int32_t D, int32_t F);
+int swc_layer_tail_pack(const void* wo_bf16, const void* w1_bf16, const void* w2_bf16, void* w_stream, int32_t D, int32_t F,
+                        void* stream);
+int swc_layer_tail(const void* attn, const float* x, float* x_out, const void* w_stream, const float* bo, const float* ln_w,
+                   const float* ln_b, float eps, const float* b1, const float* b2, const float* next_ln_w,
+                   const float* next_ln_b, void* y_next, int32_t M, int32_t D, int32_t F, void* stream);
+
+/*
  * ConvNeXt front half: depthwise Conv1d(k=7, pad=3, groups=C) + LayerNorm(eps)
  * (modules.py:1233-1239).  x: [B][T][C] f32, w: [7][C], y: [B][T][C] (y_dtype).
  */

@@ -91,7 +91,7 @@ def _register(root, name, tensor):
 
 
 class _Layer:
-    __slots__ = ("ln1", "wqkv", "bqkv", "wo", "bo", "ln2", "w1", "b1", "w2", "b2", "ws")  # ws: swc_mlp_block's operand stream (bf16)
+    __slots__ = ("ln1", "wqkv", "bqkv", "wo", "bo", "ln2", "w1", "b1", "w2", "b2", "ws", "wts")  # ws / wts: operand streams of swc_mlp_block / swc_layer_tail (bf16)
 
 
 class _Packed:
@@ -443,7 +443,7 @@ class AudioCodec(nn.Module):
 
     _TUNABLES = ("saturation_policy", "varlen_packing", "length_bucketing", "bucket_overhead_tokens", "trim_vocos", "ragged_vocos",
                  "vocos_streams", "vocos_phase_us", "vocos_split_override", "max_rows_per_call", "fused_mlp_min_rows",
-                 "fused_layer_mlp_min_rows")
+                 "fused_layer_mlp_min_rows", "layer_fusion")
 
     def replica(self):
         """A second AudioCodec over the SAME device-resident operands (nothing is copied or re-packed), with its own
@@ -542,8 +542,9 @@ class AudioCodec(nn.Module):
                 L.w1, L.b1 = W(sd[p + "fc1.weight"], dt), V(sd[p + "fc1.bias"])
                 L.w2, L.b2 = W(sd[p + "fc2.weight"], dt), V(sd[p + "fc2.bias"])
                 # the fused MLP sub-block kernel (swc_mlp_block) exists for the shipped geometry with bf16 operands
-                L.ws = (ops.mlp_pack(L.w1.w, L.w2.w)
-                        if dt == torch.bfloat16 and ops.mlp_supported(L.w1.w.shape[1], L.w1.w.shape[0]) else None)
+                ok = dt == torch.bfloat16 and ops.mlp_supported(L.w1.w.shape[1], L.w1.w.shape[0])
+                L.ws = ops.mlp_pack(L.w1.w, L.w2.w) if ok else None
+                L.wts = ops.layer_tail_pack(L.wo.w, L.w1.w, L.w2.w) if ok else None
                 out.append(L)
             return out
 
@@ -687,10 +688,14 @@ class AudioCodec(nn.Module):
             a = ops.attention(qkv, lens, B, T, H, row_start=row_start, rows=M)
             if fp8:
                 a = ops.cast_fp8(a)
-            self._mm(a, L.wo, M, D, D, lda=D, bias=L.bo, residual=h, out=h)
             F_ = L.b1.shape[0]
+            nxt = layers[i + 1].ln1 if i + 1 < len(layers) else None
+            if fused and self.layer_fusion >= 2 and getattr(L, "wts", None) is not None:
+                # out-proj + residual + LayerNorm + MLP + residual + next LayerNorm: one kernel
+                _, x = ops.layer_tail(a, h, L.wts, L.bo, L.ln2[0], L.ln2[1], 1e-5, L.b1, L.b2, M=M, D=D, F=F_, next_ln=nxt)
+                continue
+            self._mm(a, L.wo, M, D, D, lda=D, bias=L.bo, residual=h, out=h)
             if fused:
-                nxt = layers[i + 1].ln1 if i + 1 < len(layers) else None
                 _, x = ops.mlp_block(h, L.ln2[0], L.ln2[1], 1e-5, L.ws, L.b1, L.b2, M=M, D=D, F=F_, next_ln=nxt)
                 continue
             x = ops.layernorm(h, L.ln2[0], L.ln2[1], 1e-5, B=lnB, t_in=lnT, C_=D, out_dtype=dt)
@@ -702,9 +707,10 @@ class AudioCodec(nn.Module):
     # tokens from which the transformer's MLP sub-block runs as swc_mlp_block (64-token tiles, one per CU: below ~160 busy
     # CUs the two-GEMM form, whose 64/128-row tiles of N = 3072 spread over more CUs, is faster)
     fused_layer_mlp_min_rows = 64 * 160
+    layer_fusion = 2  # 2: swc_layer_tail (out-proj + MLP sub-block in one kernel); 1: swc_mlp_block behind an out-proj GEMM; 0: off
 
     def _mlp_fused(self, layers, M, dt):
-        if dt != torch.bfloat16 or M < self.fused_layer_mlp_min_rows:
+        if dt != torch.bfloat16 or M < self.fused_layer_mlp_min_rows or self.layer_fusion <= 0:
             return False
         if any(getattr(L, "ws", None) is None for L in layers):
             return False

@@ -93,11 +93,33 @@ struct MlNorm {
     const float* b;  // [D]
 };
 
-// wstream: per wave w (4 of them) NS * 192 + ML_PF fragments of 1 KiB in the order of consumption (mlp_pack_kernel)
+__device__ __forceinline__ void ml_glds16(const void* gsrc, unsigned lds_addr) {
+    // one LDS-DMA instruction: 64 lanes x 16 bytes from per-lane global addresses to 1 KiB of LDS at lds_addr (wave-uniform)
+    unsigned keep;
+    lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_addr)
+        : "memory");
+}
+
+constexpr int ML_P0 = ML_KS1 * ML_NB;  // fragments per wave of the out-proj phase (OPROJ): 48 k-steps x 6 column blocks
+static_assert(ML_P0 % ML_PF == 0, "the ring index of a fragment must not depend on the phase");
+
+// wstream: per wave w (4 of them) [OPROJ: ML_P0 +] NS * 192 + ML_PF fragments of 1 KiB in the order of consumption
+// (mlp_pack_kernel).
+// OPROJ (swc_layer_tail): the attention out-projection runs in front, in the same kernel: `att` [M][D] bf16 is the
+// attention output; the workgroup's tile of it goes to LDS by DMA, x' = x + att Wo^T + bo is accumulated IN the 192
+// registers that later accumulate fc2 (so x' never exists in memory and the residual add of the MLP is free), LayerNorm(x')
+// is taken in that transposed layout (row statistics across the 4 waves through LDS) and its bf16 fragments replace the
+// attention tile in LDS.
+template <bool OPROJ>
 __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float* xo, MlNorm ln, float eps,
                                                            const u32x4* __restrict__ wstream, const float* __restrict__ b1,
                                                            const float* __restrict__ b2, MlNorm nln,
-                                                           bf16_t* __restrict__ y_next, int M, int NS) {
+                                                           bf16_t* __restrict__ y_next, int M, int NS,
+                                                           const bf16_t* __restrict__ att, const float* __restrict__ bo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -107,7 +129,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
 
     // ---- weight stream of this wave: wave-uniform byte pointer (SGPR pair, advanced once per phase) + one 32-bit lane
     // offset + immediate
-    const long per_wave = (long)NS * (2 * ML_FPP) + ML_PF;  // fragments
+    const long per_wave = (OPROJ ? ML_P0 : 0) + (long)NS * (2 * ML_FPP) + ML_PF;  // fragments
     const char* wbase = reinterpret_cast<const char*>(wstream) + (long)w * per_wave * 1024;
     const unsigned lane_off = (unsigned)lane * 16u;
     auto wfrag = [&](int i) -> u32x4 {  // fragment i of the current phase (i may run ML_PF past its end)
@@ -116,10 +138,19 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
     };
     u32x4 ring[ML_PF];
 
+    const u32x4* ylds = reinterpret_cast<const u32x4*>(smem) + lane;
+    u32x4* hlds = reinterpret_cast<u32x4*>(smem + ML_Y_BYTES) + lane;
+    auto y_frags = [&](int s, u32x4 (&dst)[2]) {
+        if ((ML_ABL & 8) && s > 1) return;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) dst[b] = ylds[(s * 2 + b) * (ML_YP / 16)];
+    };
+    f32x16 acc2[ML_NB][2];  // [column block of this wave][token block]: out^T, 192 accumulators (AGPRs)
+
     // ---- prologue: LayerNorm of this wave's 16 tokens -> LDS as B fragments.  Fragment (s, fb) = k-step s (16 channels) x
     // token block fb (32 tokens) at [(2 s + fb)][lane][16 B]; lane l supplies token 32 fb + (l & 31), channels
     // 16 s + 8 (l >> 5) .. + 7.  A lane owns channels 256 k + 4 l .. + 3 (k = 0..2) of every row.
-    {
+    if constexpr (!OPROJ) {
         float4 v[16][3];
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -182,24 +213,135 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
             }
         }
         __syncthreads();
+    #pragma unroll
+        for (int a = 0; a < ML_NB; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.f;
+    } else {
+        // ---- OPROJ prologue.  (1) attention tile -> LDS as B fragments by DMA: fragment (s, fb) = k-step s (16 channels) x
+        // token block fb at [(2 s + fb) * ML_YP]; lane l supplies token 32 fb + (l & 31), channels 16 s + 8 (l >> 5) .. + 7
+        const unsigned lds0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem;
+#pragma unroll 4
+        for (int i = 0; i < 2 * ML_KS1 / 4; ++i) {
+            const int frag = w * (2 * ML_KS1 / 4) + i;
+            const int s_ = frag >> 1, fb = frag & 1;
+            int row = row0 + 32 * fb + lf;
+            row = row < M ? row : M - 1;  // rows beyond M are computed on a copy of the last row and never stored
+            ml_glds16(att + (long)row * ML_D + 16 * s_ + 8 * lh, lds0 + frag * ML_YP);
+        }
+        // (2) the accumulators start at the residual stream + out-proj bias, in the accumulator layout: register r = 4 g + e
+        // of tile (n, fb) in lane (lf, lh) is token 32 fb + lf, column 192 w + 32 n + 8 g + 4 lh + e
+#pragma unroll
+        for (int n = 0; n < ML_NB; ++n) {
+            if (n == ML_NB / 2) __builtin_amdgcn_sched_barrier(0);  // two halves of 24 loads: all 48 in flight + the ring spill
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = 192 * w + 32 * n + 8 * g + 4 * lh;
+                const float4 bv = *reinterpret_cast<const float4*>(bo + col);
+#pragma unroll
+                for (int fb = 0; fb < 2; ++fb) {
+                    const long row = (long)row0 + 32 * fb + lf;
+                    const float4 xv = (row < M && !(ML_ABL & 32)) ? *reinterpret_cast<const float4*>(x + row * ML_D + col)
+                                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                    acc2[n][fb][4 * g] = xv.x + bv.x; acc2[n][fb][4 * g + 1] = xv.y + bv.y;
+                    acc2[n][fb][4 * g + 2] = xv.z + bv.z; acc2[n][fb][4 * g + 3] = xv.w + bv.w;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < ML_PF; ++i) ring[i] = wfrag(i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // (3) x' = x + att Wo^T + bo: 48 k-steps of 12 MFMAs over the attention image
+        {
+            u32x4 aA[2], aB[2];
+            y_frags(0, aA);
+            auto step = [&](int s_, u32x4 (&cur)[2], u32x4 (&nxt)[2]) {
+                if (s_ + 1 < ML_KS1) y_frags(s_ + 1, nxt);
+#pragma unroll
+                for (int n = 0; n < ML_NB; ++n) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc2[n][b] = ml_mfma32(ring[(s_ * ML_NB + n) % ML_PF], cur[b], acc2[n][b]);
+                    ring[(s_ * ML_NB + n) % ML_PF] = wfrag(s_ * ML_NB + n + ML_PF);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#pragma unroll
+            for (int s_ = 0; s_ < ML_KS1; s_ += 2) {
+                step(s_, aA, aB);
+                step(s_ + 1, aB, aA);
+            }
+            wbase += ML_P0 * 1024;
+        }
+        // (4) LayerNorm(x') in the accumulator layout.  A token's 768 values sit in 2 lanes (lh) of each of the 4 waves:
+        // two-pass statistics (mean, then squared deviations), partial sums exchanged through LDS (the H buffer is free)
+        float* red = reinterpret_cast<float*>(smem + ML_Y_BYTES);
+        float sm[2], mean[2], rstd[2];
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) {
+            float t = 0.f;
+#pragma unroll
+            for (int n = 0; n < ML_NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) t += (acc2[n][fb][r] + acc2[n][fb][r + 1]) + (acc2[n][fb][r + 2] + acc2[n][fb][r + 3]);
+            sm[fb] = t + __shfl_xor(t, 32);
+        }
+        if (lh == 0) { red[w * 64 + lf] = sm[0]; red[w * 64 + 32 + lf] = sm[1]; }
+        __syncthreads();  // (every wave has also finished reading the attention image)
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) {
+            const int tk = 32 * fb + lf;
+            mean[fb] = ((red[tk] + red[64 + tk]) + (red[128 + tk] + red[192 + tk])) / (float)ML_D;
+            float t = 0.f;
+#pragma unroll
+            for (int n = 0; n < ML_NB; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    const float a0 = acc2[n][fb][r] - mean[fb], a1 = acc2[n][fb][r + 1] - mean[fb], a2 = acc2[n][fb][r + 2] - mean[fb],
+                                a3 = acc2[n][fb][r + 3] - mean[fb];
+                    t += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+                }
+            sm[fb] = t + __shfl_xor(t, 32);
+        }
+        if (lh == 0) { red[256 + w * 64 + lf] = sm[0]; red[256 + w * 64 + 32 + lf] = sm[1]; }
+        __syncthreads();
+#pragma unroll
+        for (int fb = 0; fb < 2; ++fb) {
+            const int tk = 256 + 32 * fb + lf;
+            rstd[fb] = 1.0f / sqrtf(((red[tk] + red[64 + tk]) + (red[128 + tk] + red[192 + tk])) / (float)ML_D + eps);
+        }
+        // (5) y = LayerNorm(x') as bf16 B fragments over the attention image: registers 8 t .. 8 t + 7 of tile (n, fb), rows
+        // pairwise converted, are the fragment of k-step 12 w + 2 n + t (W1 is packed in that channel order)
+#pragma unroll
+        for (int n = 0; n < ML_NB; ++n) {
+            float4 gw[4], gb[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                gw[g] = *reinterpret_cast<const float4*>(ln.w + 192 * w + 32 * n + 8 * g + 4 * lh);
+                gb[g] = *reinterpret_cast<const float4*>(ln.b + 192 * w + 32 * n + 8 * g + 4 * lh);
+            }
+#pragma unroll
+            for (int fb = 0; fb < 2; ++fb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int r = 8 * t + e;
+                        o[e] = (acc2[n][fb][r] - mean[fb]) * rstd[fb] * reinterpret_cast<const float*>(&gw[r >> 2])[r & 3] +
+                               reinterpret_cast<const float*>(&gb[r >> 2])[r & 3];
+                    }
+                    *reinterpret_cast<u32x4*>(smem + (2 * (12 * w + 2 * n + t) + fb) * ML_YP + lane * 16) =
+                        (u32x4){bf16_pack2(o[0], o[1]), bf16_pack2(o[2], o[3]), bf16_pack2(o[4], o[5]), bf16_pack2(o[6], o[7])};
+                }
+        }
+        __syncthreads();
     }
-    const u32x4* ylds = reinterpret_cast<const u32x4*>(smem) + lane;
-    u32x4* hlds = reinterpret_cast<u32x4*>(smem + ML_Y_BYTES) + lane;
-
-    f32x16 acc2[ML_NB][2];  // [column block of this wave][token block]
-#pragma unroll
-    for (int a = 0; a < ML_NB; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.f;
     f32x16 acc1[2][2];  // [hidden block][token block]: H^T of this wave's 64 hidden rows
 
-    auto y_frags = [&](int s, u32x4 (&dst)[2]) {
-        if ((ML_ABL & 8) && s > 1) return;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) dst[b] = ylds[(s * 2 + b) * (ML_YP / 16)];
-    };
     auto h_frags = [&](int q, u32x4 (&dst)[2]) {
         if ((ML_ABL & 8) && q > 1) return;
 #pragma unroll
@@ -342,7 +484,8 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
             const long row = (long)row0 + 32 * p + 8 * w + i;
 #pragma unroll
             for (int k = 0; k < 3; ++k)
-                rr[i][k] = row < M ? *reinterpret_cast<const float4*>(x + row * ML_D + 256 * k + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rr[i][k] = (!OPROJ && row < M) ? *reinterpret_cast<const float4*>(x + row * ML_D + 256 * k + 4 * lane)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);  // (OPROJ: the accumulators hold x' already)
         }
 #pragma unroll
         for (int n = 0; n < ML_NB; ++n)
@@ -405,25 +548,35 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
     }
 }
 
-// One thread per 16-byte chunk of the packed stream.  Stream of wave w: phases of 96 fragments in the order of consumption
-// G1(0), G1(1), G2(0), G1(2), G2(1), ..., G1(NS-1), G2(NS-2), G2(NS-1), then ML_PF zero fragments (read ahead, never used).
-//   G1(j), fragment i: k-step s = i / 2, hidden block hb = i % 2: W1 rows 256 j + 64 w + 32 hb + (lane & 31),
-//                      columns 16 s + 8 (lane >> 5) .. + 7
+// One thread per 16-byte chunk of the packed stream.  Stream of wave w: [with wo: the out-proj phase P0 of ML_P0 fragments,]
+// then phases of 96 fragments in the order of consumption G1(0), G1(1), G2(0), G1(2), G2(1), ..., G1(NS-1), G2(NS-2),
+// G2(NS-1), then ML_PF zero fragments (read ahead, never used).
+//   P0,    fragment i: k-step s = i / 6, column block n = i % 6: Wo rows 192 w + 32 n + (lane & 31), columns
+//                      16 s + 8 (lane >> 5) .. + 7 (the attention tile arrives by DMA in natural channel order)
+//   G1(j), fragment i: k-step s = i / 2, hidden block hb = i % 2: W1 rows 256 j + 64 w + 32 hb + (lane & 31), columns
+//                      16 s + 8 (lane >> 5) .. + 7, or — with wo, where y comes out of the accumulators —
+//                      16 s + 4 (lane >> 5) + {0..3, 8..11}
 //   G2(j), fragment i: k-step q = i / 6, column block n = i % 6: W2 rows 192 w + 32 n + (lane & 31), hidden values
 //                      256 j + 16 q + 4 (lane >> 5) + {0..3, 8..11}: the order GEMM1's accumulators convert in place
-__global__ void mlp_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2, uint4* __restrict__ out, int NS) {
-    const long per_wave = (long)NS * (2 * ML_FPP) + ML_PF;
+__global__ void mlp_pack_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2,
+                                uint4* __restrict__ out, int NS) {
+    const long p0 = wo ? ML_P0 : 0;
+    const long per_wave = p0 + (long)NS * (2 * ML_FPP) + ML_PF;
     const long total = 4 * per_wave * 64;
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
     const int lane = (int)(id & 63);
     const long f_all = id >> 6;
     const int w = (int)(f_all / per_wave);
-    const long f = f_all - (long)w * per_wave;
+    long f = f_all - (long)w * per_wave;
     const int lf = lane & 31, lh = lane >> 5;
     const long F = (long)NS * ML_SL;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (f < (long)NS * (2 * ML_FPP)) {
+    if (f < p0) {
+        const int s = (int)(f / ML_NB), n = (int)(f % ML_NB);
+        v = *reinterpret_cast<const uint4*>(wo + (long)(192 * w + 32 * n + lf) * ML_D + 16 * s + 8 * lh);
+    } else if (f - p0 < (long)NS * (2 * ML_FPP)) {
+        f -= p0;
         // phase p: 0 -> G1(0); 2k-1 -> G1(k), 2k -> G2(k-1) for k = 1..NS-1; 2NS-1 -> G2(NS-1)
         const int p = (int)(f / ML_FPP), i = (int)(f % ML_FPP);
         const bool is_g1 = p == 0 || ((p & 1) && p < 2 * NS - 1);
@@ -431,7 +584,13 @@ __global__ void mlp_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __r
             const int j = p == 0 ? 0 : (p + 1) >> 1;
             const int s = i >> 1, hb = i & 1;
             const long row = (long)j * ML_SL + 64 * w + 32 * hb + lf;  // hidden row
-            v = *reinterpret_cast<const uint4*>(w1 + row * ML_D + 16 * s + 8 * lh);
+            if (wo) {
+                const uint2 lo = *reinterpret_cast<const uint2*>(w1 + row * ML_D + 16 * s + 4 * lh);
+                const uint2 hi = *reinterpret_cast<const uint2*>(w1 + row * ML_D + 16 * s + 4 * lh + 8);
+                v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            } else {
+                v = *reinterpret_cast<const uint4*>(w1 + row * ML_D + 16 * s + 8 * lh);
+            }
         } else {
             const int j = p == 2 * NS - 1 ? NS - 1 : (p >> 1) - 1;
             const int q = i / ML_NB, n = i % ML_NB;
@@ -445,6 +604,18 @@ __global__ void mlp_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __r
     out[id] = v;
 }
 
+int ml_pack(const void* wo, const void* w1, const void* w2, void* stream_out, int32_t D, int32_t F, void* stream, const char* who) {
+    SWC_CHECK_ARG(w1 && w2 && stream_out, "%s: null pointer", who);
+    SWC_CHECK_ARG(D == ML_D && F > 0 && F % ML_SL == 0, "%s: needs D = %d and F a multiple of %d (D=%d F=%d)", who, ML_D, ML_SL, D, F);
+    SWC_CHECK_ARG(aligned16(wo) && aligned16(w1) && aligned16(w2) && aligned16(stream_out), "%s: unaligned", who);
+    const int NS = F / ML_SL;
+    const long total = 4L * ((wo ? ML_P0 : 0) + (long)NS * (2 * ML_FPP) + ML_PF) * 64;
+    hipLaunchKernelGGL(mlp_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)wo, (const bf16_t*)w1, (const bf16_t*)w2, (uint4*)stream_out, NS);
+    SWC_CHECK_LAUNCH(who);
+    return SWC_OK;
+}
+
 }  // namespace
 
 extern "C" int64_t swc_mlp_stream_bytes(int32_t D, int32_t F) {
@@ -453,16 +624,7 @@ extern "C" int64_t swc_mlp_stream_bytes(int32_t D, int32_t F) {
 }
 
 extern "C" int swc_mlp_pack(const void* w1, const void* w2, void* stream_out, int32_t D, int32_t F, void* stream) {
-    SWC_CHECK_ARG(w1 && w2 && stream_out, "swc_mlp_pack: null pointer");
-    SWC_CHECK_ARG(D == ML_D && F > 0 && F % ML_SL == 0, "swc_mlp_pack: needs D = %d and F a multiple of %d (D=%d F=%d)", ML_D,
-                  ML_SL, D, F);
-    SWC_CHECK_ARG(aligned16(w1) && aligned16(w2) && aligned16(stream_out), "swc_mlp_pack: unaligned");
-    const int NS = F / ML_SL;
-    const long total = 4L * ((long)NS * (2 * ML_FPP) + ML_PF) * 64;
-    hipLaunchKernelGGL(mlp_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)w1, (const bf16_t*)w2, (uint4*)stream_out, NS);
-    SWC_CHECK_LAUNCH("swc_mlp_pack");
-    return SWC_OK;
+    return ml_pack(nullptr, w1, w2, stream_out, D, F, stream, "swc_mlp_pack");
 }
 
 extern "C" int swc_mlp_block(const float* x, float* x_out, const float* ln_w, const float* ln_b, float eps,
@@ -477,10 +639,45 @@ extern "C" int swc_mlp_block(const float* x, float* x_out, const float* ln_w, co
                       aligned16(b2) && aligned16(next_ln_w) && aligned16(next_ln_b) && aligned16(y_next),
                   "swc_mlp_block: unaligned");
     if (M == 0) return SWC_OK;
-    SWC_ENABLE_LDS(mlp_block_kernel, ML_LDS, "swc_mlp_block");
+    SWC_ENABLE_LDS(mlp_block_kernel<false>, ML_LDS, "swc_mlp_block");
     const unsigned grid = (unsigned)((M + ML_BM - 1) / ML_BM);
-    hipLaunchKernelGGL(mlp_block_kernel, dim3(grid), dim3(256), ML_LDS, (hipStream_t)stream, x, x_out, MlNorm{ln_w, ln_b}, eps,
-                       (const u32x4*)w_stream, b1, b2, MlNorm{next_ln_w, next_ln_b}, (bf16_t*)y_next, M, F / ML_SL);
+    hipLaunchKernelGGL(mlp_block_kernel<false>, dim3(grid), dim3(256), ML_LDS, (hipStream_t)stream, x, x_out, MlNorm{ln_w, ln_b},
+                       eps, (const u32x4*)w_stream, b1, b2, MlNorm{next_ln_w, next_ln_b}, (bf16_t*)y_next, M, F / ML_SL,
+                       (const bf16_t*)nullptr, (const float*)nullptr);
     SWC_CHECK_LAUNCH("swc_mlp_block");
+    return SWC_OK;
+}
+
+extern "C" int64_t swc_layer_tail_stream_bytes(int32_t D, int32_t F) {
+    if (D != ML_D || F <= 0 || F % ML_SL != 0) return 0;
+    return 4L * (ML_P0 + (long)(F / ML_SL) * (2 * ML_FPP) + ML_PF) * 1024;
+}
+
+extern "C" int swc_layer_tail_pack(const void* wo, const void* w1, const void* w2, void* stream_out, int32_t D, int32_t F,
+                                   void* stream) {
+    SWC_CHECK_ARG(wo, "swc_layer_tail_pack: null pointer");
+    return ml_pack(wo, w1, w2, stream_out, D, F, stream, "swc_layer_tail_pack");
+}
+
+extern "C" int swc_layer_tail(const void* attn, const float* x, float* x_out, const void* w_stream, const float* bo,
+                              const float* ln_w, const float* ln_b, float eps, const float* b1, const float* b2,
+                              const float* next_ln_w, const float* next_ln_b, void* y_next, int32_t M, int32_t D, int32_t F,
+                              void* stream) {
+    SWC_CHECK_ARG(attn && x && x_out && bo && ln_w && ln_b && w_stream && b1 && b2, "swc_layer_tail: null pointer");
+    SWC_CHECK_ARG(!y_next || (next_ln_w && next_ln_b), "swc_layer_tail: y_next needs next_ln_w / next_ln_b");
+    SWC_CHECK_ARG(D == ML_D && F > 0 && F % ML_SL == 0, "swc_layer_tail: needs D = %d and F a multiple of %d (D=%d F=%d)", ML_D,
+                  ML_SL, D, F);
+    SWC_CHECK_ARG(M >= 0, "swc_layer_tail: bad M");
+    SWC_CHECK_ARG(aligned16(attn) && aligned16(x) && aligned16(x_out) && aligned16(bo) && aligned16(ln_w) && aligned16(ln_b) &&
+                      aligned16(w_stream) && aligned16(b1) && aligned16(b2) && aligned16(next_ln_w) && aligned16(next_ln_b) &&
+                      aligned16(y_next),
+                  "swc_layer_tail: unaligned");
+    if (M == 0) return SWC_OK;
+    SWC_ENABLE_LDS(mlp_block_kernel<true>, ML_LDS, "swc_layer_tail");
+    const unsigned grid = (unsigned)((M + ML_BM - 1) / ML_BM);
+    hipLaunchKernelGGL(mlp_block_kernel<true>, dim3(grid), dim3(256), ML_LDS, (hipStream_t)stream, x, x_out, MlNorm{ln_w, ln_b},
+                       eps, (const u32x4*)w_stream, b1, b2, MlNorm{next_ln_w, next_ln_b}, (bf16_t*)y_next, M, F / ML_SL,
+                       (const bf16_t*)attn, bo);
+    SWC_CHECK_LAUNCH("swc_layer_tail");
     return SWC_OK;
 }

@@ -897,3 +897,51 @@ def test_mlp_block_out_of_place_and_errors():
     assert not ops.mlp_supported(512, 2048) and not ops.mlp_supported(768, 3000) and ops.mlp_supported(768, 3072)
     with pytest.raises(SwcError):
         ops.mlp_pack(w1[:, :512].contiguous(), w2[:512].contiguous())
+
+
+@pytest.mark.parametrize("M,F_,with_next", [(64, 256, True), (300, 512, True), (77, 256, False), (1000, 3072, True),
+                                            (16000, 3072, True)])
+def test_layer_tail_fused(M, F_, with_next):
+    """swc_layer_tail (out-proj + residual + LayerNorm + fc1 + GELU + fc2 + residual + the next LayerNorm in one kernel,
+    modules.py:219-232,216) vs (a) an f64 evaluation on the same bf16 operands and (b) the launches it replaces (swc_gemm
+    out-proj, swc_mlp_block).  M covers partial 64-token tiles; in place."""
+    ops = _ops()
+    D = 768
+    g = torch.Generator().manual_seed(M * 5 + F_)
+    x0 = torch.randn(M, D, generator=g) * 1.5 + 0.1
+    att = (torch.randn(M, D, generator=g) * 0.7).to(torch.bfloat16)
+    wo = (torch.randn(D, D, generator=g) * D ** -0.5).to(torch.bfloat16)
+    bo = torch.randn(D, generator=g) * 0.2
+    lw, lb = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    nw, nb = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    w1 = (torch.randn(F_, D, generator=g) * D ** -0.5).to(torch.bfloat16)
+    w2 = (torch.randn(D, F_, generator=g) * F_ ** -0.5).to(torch.bfloat16)
+    b1, b2 = torch.randn(F_, generator=g) * 0.3, torch.randn(D, generator=g) * 0.3
+    d = lambda t: t.to(DEV)
+    wts = ops.layer_tail_pack(d(wo), d(w1), d(w2))
+    x = d(x0).clone()
+    xo, yn = ops.layer_tail(d(att), x, wts, d(bo), d(lw), d(lb), 1e-5, d(b1), d(b2), M=M, D=D, F=F_,
+                            next_ln=(d(nw), d(nb)) if with_next else None)
+    assert xo.data_ptr() == x.data_ptr() and torch.isfinite(xo).all()
+    # (b) the launches it replaces
+    x2 = d(x0).clone()
+    ops.gemm(d(att), d(wo), M, D, D, bias=d(bo), residual=x2, out=x2)
+    ws = ops.mlp_pack(d(w1), d(w2))
+    _, yn2 = ops.mlp_block(x2, d(lw), d(lb), 1e-5, ws, d(b1), d(b2), M=M, D=D, F=F_, next_ln=(d(nw), d(nb)) if with_next else None)
+    # (a) f64
+    xp = x0.double() + att.double() @ wo.double().T + bo.double()
+    yr = F.layer_norm(xp, (D,), lw.double(), lb.double(), 1e-5)
+    h = F.gelu(yr @ w1.double().T + b1.double())
+    ref = xp + h @ w2.double().T + b2.double()
+    scale = float((ref - x0.double()).abs().max())
+    e_ref = float((xo.cpu().double() - ref).abs().max()) / scale
+    e_two = float((xo.cpu().double() - x2.cpu().double()).abs().max()) / scale
+    e_two_ref = float((x2.cpu().double() - ref).abs().max()) / scale
+    assert e_ref < 1e-2, (e_ref, e_two_ref)
+    assert e_ref < 2.0 * e_two_ref + 1e-4, (e_ref, e_two_ref)
+    assert e_two < 5e-3, e_two
+    if with_next:
+        want = ops.layernorm(xo, d(nw), d(nb), 1e-5, B=1, t_in=M, C_=D, out_dtype=torch.bfloat16).view(M, D)
+        assert torch.equal(yn, want)     # LayerNorm_next of the kernel's own x_out: the arithmetic of swc_layernorm
+    else:
+        assert yn is None

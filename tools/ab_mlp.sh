@@ -4,6 +4,6 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
 for rep in 1 2; do
   for tag in "$@"; do
-    echo "== $tag"; SWC_LIB=$R/simwhisper_codec_amd/libswc_$tag.so python tools/bench_mlp.py 2>/dev/null | grep -E "^fused"
+    echo "== $tag"; SWC_LIB=$R/simwhisper_codec_amd/libswc_$tag.so python tools/bench_mlp.py 2>/dev/null | grep -E "^fused|^layer_tail|^oproj"
   done
 done

@@ -17,6 +17,10 @@ w2 = (torch.randn(D, F_, device=dev, generator=g) * F_ ** -0.5).to(torch.bfloat1
 b1, b2 = torch.randn(F_, device=dev) * 0.1, torch.randn(D, device=dev) * 0.1
 lw, lb = 1 + 0.2 * torch.randn(D, device=dev), 0.1 * torch.randn(D, device=dev)
 ws = ops.mlp_pack(w1, w2)
+wo = (torch.randn(D, D, device=dev, generator=g) * D ** -0.5).to(torch.bfloat16)
+bo = torch.randn(D, device=dev) * 0.1
+wts = ops.layer_tail_pack(wo, w1, w2)
+att = [(torch.randn(M, D, device=dev, generator=g) * 0.5).to(torch.bfloat16) for _ in range(NB)]
 hh = torch.empty(M, F_, device=dev, dtype=torch.bfloat16)
 yb = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
 yn = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
@@ -44,7 +48,23 @@ def two_gemm(i):
     ops.gemm(hh, w2, M, D, F_, bias=b2, residual=x, out=x)
 
 
-ALL = (("fused", fused), ("fused_no_next", fused_no_next), ("ln+2gemm+ln", four), ("two_gemm", two_gemm))
+def tail(i):  # out-proj + the whole MLP sub-block + next LayerNorm: one kernel
+    ops.layer_tail(att[i % NB], xs[i % NB], wts, bo, lw, lb, 1e-5, b1, b2, M=M, D=D, F=F_, next_ln=(lw, lb), y_next=yn)
+
+
+def oproj_fused(i):  # the same work as two launches: out-proj GEMM, swc_mlp_block
+    x = xs[i % NB]
+    ops.gemm(att[i % NB], wo, M, D, D, bias=bo, residual=x, out=x)
+    ops.mlp_block(x, lw, lb, 1e-5, ws, b1, b2, M=M, D=D, F=F_, next_ln=(lw, lb), y_next=yn)
+
+
+def oproj_four(i):  # ... and as the five launches of round 3
+    x = xs[i % NB]
+    ops.gemm(att[i % NB], wo, M, D, D, bias=bo, residual=x, out=x)
+    four(i)
+
+
+ALL = (("layer_tail", tail), ("oproj+fused", oproj_fused), ("oproj+ln+2gemm+ln", oproj_four), ("fused", fused), ("fused_no_next", fused_no_next), ("ln+2gemm+ln", four), ("two_gemm", two_gemm))
 res = {n: [] for n, _ in ALL}
 for _, fn in ALL:
     for i in range(3):
@@ -61,4 +81,4 @@ for rnd in range(7):
 fl = 4.0 * M * D * F_
 for name, ts in res.items():
     t = statistics.median(ts)
-    print(f"{name:14s} M={M} {t*1e3:8.1f} us  {fl/t/1e9:8.1f} TFLOP/s   (min {min(ts)*1e3:.1f} us)")
+    print(f"{name:18s} M={M} {t*1e3:8.1f} us  {fl/t/1e9:8.1f} TFLOP/s   (min {min(ts)*1e3:.1f} us)")

@@ -6,7 +6,7 @@ import os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch, yaml
-from bench import bench_inputs, cpu_model
+from bench import bench_inputs, cpu_allotment, cpu_model
 from oracle.ref_cpu import Oracle
 from simwhisper_codec_amd import synth
 
@@ -14,9 +14,11 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 gp = yaml.safe_load(open(os.path.join(ROOT, "config", "SimWhisperCodec.yaml")))["generator_params"]
 ora = Oracle(gp, synth.synth_state_dict(gp))
 wavs = bench_inputs(B, 160000)
-visible = len(os.sched_getaffinity(0))
-print(f"cpu: {cpu_model()}; os.cpu_count() = {os.cpu_count()}; visible to this process (sched_getaffinity) = {visible}")
-counts = sorted({c for c in (4, 8, 16, 32, 64, visible) if c <= visible})
+visible, quota = cpu_allotment()
+print(f"cpu: {cpu_model()}; os.cpu_count() = {os.cpu_count()}; affinity mask (sched_getaffinity) = {visible} logical CPUs; "
+      f"cgroup cpu quota = {quota} CPUs; bench.py uses min(mask, quota) = {min(visible, int(quota) if quota else visible)} threads")
+use = min(visible, int(quota) if quota else visible)
+counts = sorted({c for c in (use // 4, use // 2, use, 2 * use) if 1 <= c <= visible})
 for n in counts:
     torch.set_num_threads(n)
     ts = []
