@@ -945,3 +945,4 @@ def test_layer_tail_fused(M, F_, with_next):
         assert torch.equal(yn, want)     # LayerNorm_next of the kernel's own x_out: the arithmetic of swc_layernorm
     else:
         assert yn is None
+

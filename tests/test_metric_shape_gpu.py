@@ -7,7 +7,7 @@ run their small-grid geometries and no persistent tile walk happens.  BASELINE.j
 
   * the fused ConvNeXt kernel is FORCED on the reference-generated fixtures (`fused_mlp_min_rows = 0`; it handles partial
     tiles) and compared with the reference's own stage output / waveforms (tests/golden, written by the reference itself);
-    the same for the fused transformer-MLP kernel of the decoder (`fused_layer_mlp_min_rows = 0`, swc_mlp_block: round 4);
+    the same for the fused transformer-layer kernels of the decoder (`fused_layer_mlp_min_rows = 0`: swc_layer_tail, swc_mlp_block; round 4);
   * the metric shapes run as `bench.py` runs them (same generator, same seed) and single rows are compared with the CPU
     oracle run on that row alone: uniform batches, so a row's result does not depend on the batch — codes bit for bit,
     waveform within the bf16-decode tolerance (modules.py:1229-1248, model.py:244-373).
@@ -71,27 +71,30 @@ def test_stage_vocos_fused_block_kernel(name):
     assert e < STAGE_TOL["y"][1], e
 
 
+@pytest.mark.parametrize("fusion", [2, 1])
 @pytest.mark.parametrize("name", ["single", "ragged"])
-def test_stage_decoder_fused_mlp_kernel(name):
-    """The 12 decoder layers + deconvs fed the reference's up-sampler output, every MLP sub-block on swc_mlp_block (which
-    also replaces the LayerNorm launches around it), against the reference's own decoder output (st_dec_mel) at the stage's
-    tolerance.  `ragged` runs the packed token layout."""
+def test_stage_decoder_fused_mlp_kernel(name, fusion):
+    """The 12 decoder layers + deconvs fed the reference's up-sampler output, everything behind the attention of every layer on
+    swc_layer_tail (fusion 2: out-proj + MLP sub-block + both LayerNorms in one kernel) or the MLP sub-block on swc_mlp_block
+    behind an out-proj GEMM (fusion 1), against the reference's own decoder output (st_dec_mel) at the stage's tolerance.
+    `ragged` runs the packed token layout."""
     g, m = golden("real", name), model("real", "mixed")
     up = torch.from_numpy(g["st_up"]).transpose(1, 2).contiguous().to(DEV)  # [B, 4T, D]
     B, Tt, D = up.shape
     lat = [int(v) for v in g["st_code_lens"]]
-    keep = m.fused_layer_mlp_min_rows
+    keep, keep_f = m.fused_layer_mlp_min_rows, m.layer_fusion
     try:
-        m.fused_layer_mlp_min_rows = 0
-        with torch.cuda.device(0), torch.inference_mode(), _Spy("mlp_block") as spy, _Spy("layernorm") as ln:
+        m.fused_layer_mlp_min_rows, m.layer_fusion = 0, fusion
+        with torch.cuda.device(0), torch.inference_mode(), _Spy("mlp_block") as spy1, _Spy("layer_tail") as spy2, \
+                _Spy("layernorm") as ln:
             P = m._packed()
             mel = m._decoder(up.reshape(B * Tt, D).clone(), lat, B, Tt, P).float().cpu().numpy()
     finally:
-        m.fused_layer_mlp_min_rows = keep
-    assert spy.calls == len(P.dec_layers) == 12
+        m.fused_layer_mlp_min_rows, m.layer_fusion = keep, keep_f
+    assert (spy1.calls, spy2.calls) == ((0, 12) if fusion == 2 else (12, 0)) and len(P.dec_layers) == 12
     assert ln.calls == 2   # the first layer's self_attn_layer_norm and the decoder's final LayerNorm; 24 are folded away
     e = _relerr(mel, g["st_dec_mel"].transpose(0, 2, 1))
-    _report(f"stage/dec_mel_fused_mlp/real/{name}/mixed", rel_err=e, tokens=B * Tt)
+    _report(f"stage/dec_mel_fused_mlp/real/{name}/mixed/fusion{fusion}", rel_err=e, tokens=B * Tt)
     assert e < STAGE_TOL["dec_mel"][1], e
 
 
@@ -106,7 +109,7 @@ def test_decode_waveform_fused_block_kernel(name):
     keep, keep_l = m.fused_mlp_min_rows, m.fused_layer_mlp_min_rows
     try:
         m.fused_mlp_min_rows = m.fused_layer_mlp_min_rows = 0
-        with _Spy("convnext_block") as spy, _Spy("dwconv7_ln") as old, _Spy("mlp_block") as mlp:
+        with _Spy("convnext_block") as spy, _Spy("dwconv7_ln") as old, _Spy("layer_tail") as mlp:
             dec = m.decode(codes, overlap_seconds=10)
     finally:
         m.fused_mlp_min_rows, m.fused_layer_mlp_min_rows = keep, keep_l
@@ -159,12 +162,12 @@ def test_metric_shape_32x10s_against_oracle():
     m = model("real", "mixed")
     wavs = _bench_inputs(32, 10.0)
     dw = [w.to(DEV) for w in wavs]
-    with _Spy("convnext_block") as spy, _Spy("dwconv7_ln") as old, _Spy("mlp_block") as mlp:
+    with _Spy("convnext_block") as spy, _Spy("dwconv7_ln") as old, _Spy("layer_tail") as mlp:
         codes = m.encode(dw, overlap_seconds=10)["codes_list"]
         out = m.decode(codes, overlap_seconds=10)["syn_wav_list"]
     assert spy.calls == 24 and old.calls == 0          # one fused launch per block over 32 000 frames: the metric's kernels
     assert spy.kw[0] == {"B": 32, "T": 1000}
-    assert mlp.calls == 12                             # the decoder's 12 MLP sub-blocks (16 000 tokens) on swc_mlp_block
+    assert mlp.calls == 12                             # the decoder's 12 layers (16 000 tokens): everything behind the attention on swc_layer_tail
     assert all(tuple(c.shape) == (8, 125) for c in codes) and all(w.shape[0] == 160000 for w in out)
     _check_rows_against_oracle("32x10s", wavs, codes, out, rows=(0, 31))
 
@@ -212,7 +215,7 @@ def test_config1_8x10s_bf16_against_oracle():
     levels within the preset's floors; the decoder, given the ORACLE's codes for the whole batch, within the bf16 tolerance."""
     m = model("real", "bf16")
     wavs = _bench_inputs(8, 10.0)
-    with _Spy("convnext_block") as fused, _Spy("dwconv7_ln") as two, _Spy("mlp_block") as mlp:
+    with _Spy("convnext_block") as fused, _Spy("dwconv7_ln") as two, _Spy("layer_tail") as mlp:
         codes = m.encode([w.to(DEV) for w in wavs], overlap_seconds=10)["codes_list"]
         o, want = _levels_against_oracle("8x10s_bf16", "bf16", wavs, codes, rows=(0, 7))
         # decode the oracle's codes of rows 0 and 7 inside a batch of 8 (the other rows: this preset's own codes)
@@ -232,7 +235,7 @@ def test_config4_32x10s_fp8_against_oracle():
     preset's floors; waveform given the oracle's codes within the bf16 tolerance."""
     m = model("real", "fp8")
     wavs = _bench_inputs(32, 10.0)
-    with _Spy("convnext_block") as fused, _Spy("mlp_block") as mlp:
+    with _Spy("convnext_block") as fused, _Spy("layer_tail") as mlp:
         codes = m.encode([w.to(DEV) for w in wavs], overlap_seconds=10)["codes_list"]
         o, want = _levels_against_oracle("32x10s_fp8", "fp8", wavs, codes, rows=(0, 31))
         mix = [want[r].to(DEV).to(codes[r].dtype) if r in want else codes[r] for r in range(32)]
