@@ -51,7 +51,7 @@ def build_parser():
     p.add_argument("--batch_size", type=int, default=8)
     p.add_argument("--input_dir", type=str, default="input_wavs")
     p.add_argument("--output_dir", type=str, default="output_wavs")
-    p.add_argument("--precision", type=str, default="mixed", choices=["fp32", "mixed", "mixed_f32", "bf16", "fp8"])
+    p.add_argument("--precision", type=str, default="mixed", choices=["fp32", "mixed", "mixed_f32", "bf16", "fp8", "fp8_fc1", "f16s"])
     p.add_argument("--synthetic_checkpoint", action="store_true",
                    help="ignore --checkpoint_path and use the closed-form synthetic weights (offline testing)")
     p.add_argument("--in_flight", type=int, default=2,

@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--synthetic", action="store_true")
     ap.add_argument("--out", required=True)
     ap.add_argument("--fold", action="store_true", help="write GEMM-ready operands (needs the GPU)")
-    ap.add_argument("--precision", default="mixed", choices=["fp32", "mixed", "mixed_f32", "bf16", "fp8"])
+    ap.add_argument("--precision", default="mixed", choices=["fp32", "mixed", "mixed_f32", "bf16", "fp8", "fp8_fc1", "f16s"])
     ap.add_argument("--device", default="cuda:0")
     args = ap.parse_args()
     gp = yaml.safe_load(open(args.config))["generator_params"]
