@@ -145,7 +145,8 @@ def test_vs_oracle_fresh_input():
 # values measured on MI355X with the synthetic checkpoint (real config, 8 x 5 s fresh utterances):
 #   bf16: 98.7 % of levels equal (95.1 % of codes), none off by more than 1;   fp8: 87.0 % equal (58 % of codes), 99.8 % within 1.
 #   fp8_fc1 (fc1 + GELU of the encoder alone in fp8; round 3's CPU simulation predicted 95.4 % equal levels): floors at bf16's class
-LEVEL_FLOORS = {"bf16": (0.97, 0.9995), "fp8": (0.84, 0.995), "fp8_fc1": (0.95, 0.9995)}
+#   measured on MI355X: 95.1 % equal (81.6 % of codes), all within 1
+LEVEL_FLOORS = {"bf16": (0.97, 0.9995), "fp8": (0.84, 0.995), "fp8_fc1": (0.94, 0.9995)}
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp8", "fp8_fc1"])
