@@ -13,7 +13,7 @@ import sys
 root = sys.argv[1]
 FAM = [("gemm_kernel<0", "gemm_f32"), ("gemm_kernel<1", "gemm_bf16"), ("gemm_kernel<2", "gemm_f16s"),
        ("attn16_kernel<1>", "attention_bf16"), ("attn16_kernel<2>", "attention_f16s"),
-       ("convnext_mlp_kernel", "convnext_bf16")]
+       ("convnext_mlp_kernel", "convnext_bf16"), ("mlp_block_kernel", "mlp_bf16")]
 acc = collections.defaultdict(lambda: collections.defaultdict(float))
 n = collections.Counter()
 for f in glob.glob(f"{root}/**/*counter_collection.csv", recursive=True):

@@ -10,7 +10,7 @@ import sys
 
 root = sys.argv[1]
 FAM = {"gemm_kernel<0": "gemm_f32", "gemm_kernel<1": "gemm_bf16", "gemm_kernel<2": "gemm_f16s", "gemm_kernel<3": "gemm_fp8",
-       "convnext_mlp_kernel": "convnext_bf16", "dwconv7_ln_kernel": "dwconv7_ln", "attn16_kernel<1>": "attention_bf16",
+       "convnext_mlp_kernel": "convnext_bf16", "mlp_block_kernel": "mlp_bf16", "dwconv7_ln_kernel": "dwconv7_ln", "attn16_kernel<1>": "attention_bf16",
        "attn16_kernel<2>": "attention_f16s", "layernorm_kernel": "layernorm", "snake_aa_kernel": "snake_aa",
        "istft_ola_kernel": "istft_ola", "mel_frames_kernel": "mel_frames"}
 

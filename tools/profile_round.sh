@@ -2,7 +2,7 @@
 # One evidence pass on the GPU box (from the repo root): rocprofv3 kernel stats of the bench command, PMC HBM traffic,
 # MFMA utilisation, per-stage device times, HBM micro-bench.  usage: bash tools/profile_round.sh <tag> [commit]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-tag=${1:-r02}
+tag=${1:-r04}
 export SWC_COMMIT=${2:-unknown} SWC_PROFILE_TAG=$tag
 out=$R/gpurun_out/$tag
 mkdir -p $out
@@ -28,7 +28,7 @@ for k, v in (d.get('other_configs') or {}).items():
     r=(v.get('roofline') or {})
     print(json.dumps({'config': k, 'value': v.get('value'), 'ms_per_step': v.get('ms_per_step'), 'dominant': r.get('kernel'), 'achieved': r.get('achieved'), 'frac': r.get('frac'), 'other': {a: b['TFLOP/s'] for a, b in (r.get('other') or {}).items()}, 'error': v.get('error')}))
 " > $out/other_configs.jsonl
-for spec in "--precision bf16" "--precision mixed_f32"; do
+for spec in "--precision bf16" "--precision fp8_fc1" "--precision f16s"; do
   python3 bench.py --steps 6 --warmup 2 --cpu-baseline off --no-dist --no-inflight --other-configs off $spec 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d.get('roofline',{})
