@@ -173,10 +173,13 @@ int swc_pack_rows(const void* src, void* dst, const int32_t* row_start, const in
  * `w_stream` is the pair (pwconv1.weight [I][C], pwconv2.weight [C][I]) in bf16, re-ordered ONCE at load by
  * swc_convnext_pack into the order in which each wave consumes 1 KiB MFMA operand fragments
  * (swc_convnext_stream_bytes(C, I) bytes, 0 for an unsupported geometry).  bf16 operands, f32 accumulation; GELU is the
- * refit sigmoid form of the bf16 swc_gemm epilogue (|error| <= 2.7e-4).
+ * refit sigmoid form of the bf16 swc_gemm epilogue (|error| <= 2.7e-4).  The pack step takes the block's gamma: builds with
+ * -DCX_RES_ACC=1 (a measured build option, not the default) fold it into pwconv2's rows and start pwconv2's accumulators at
+ * x + gamma * b2; the gamma / b2 arguments of swc_convnext_mlp / swc_convnext_block must be the ones the stream was packed with.
  */
 int64_t swc_convnext_stream_bytes(int32_t C, int32_t I);
-int swc_convnext_pack(const void* w1_bf16, const void* w2_bf16, void* w_stream, int32_t C, int32_t I, void* stream);
+int swc_convnext_pack(const void* w1_bf16, const void* w2_bf16, const float* gamma, void* w_stream, int32_t C, int32_t I,
+                      void* stream);
 int swc_convnext_mlp(const void* y, const void* w_stream, const float* b1, const float* b2, const float* gamma,
                      float* x, int32_t M, int32_t C, int32_t I, void* stream);
 /*

@@ -70,7 +70,7 @@ SIGNATURES = {
     "swc_set_saturation_counter": [_P],
     "swc_delay_us": [_I, _P],
     "swc_pack_rows": [_P, _P, _P, _P, _I, _I, _L, _P],
-    "swc_convnext_pack": [_P, _P, _P, _I, _I, _P],
+    "swc_convnext_pack": [_P, _P, _P, _P, _I, _I, _P],
     "swc_convnext_mlp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "swc_convnext_block": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "swc_mlp_pack": [_P, _P, _P, _I, _I, _P],

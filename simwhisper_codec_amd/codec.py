@@ -651,7 +651,7 @@ class AudioCodec(nn.Module):
                 w2=W(sd[b_ + "pwconv2.weight"], ddt), b2=V(sd[b_ + "pwconv2.bias"]), g=V(sd[b_ + "gamma"])))
             if P.fused_mlp:
                 blk = P.blocks[-1]
-                blk["ws"] = ops.convnext_pack(blk["w1"].w, blk["w2"].w)
+                blk["ws"] = ops.convnext_pack(blk["w1"].w, blk["w2"].w, blk["g"])
         # frames a kept sample can depend on: embed k7 (+-3), one depthwise k7 per block (+-3 each), ISTFT overlap (+-3)
         if self.VOCOS_HALO_FRAMES < 3 * (v["num_layers"] + 1) + 3:
             raise SwcError(f"VOCOS_HALO_FRAMES = {self.VOCOS_HALO_FRAMES} is too small for {v['num_layers']} ConvNeXt blocks "

@@ -48,6 +48,16 @@ constexpr int CX_TLD = CX_C + 4;  // row pitch (floats) of the epilogue transpos
 #ifndef CX_EPI_PREFETCH
 #define CX_EPI_PREFETCH 1
 #endif
+// CX_RES_ACC (round 4, build option for the 32 x 32 x 16 kernel; measured, parity-green, NOT the default): the residual lives in
+// the accumulators.  gamma is folded into W2 at pack time (swc_convnext_pack) and GEMM2's accumulators START at x + gamma * b2
+// (loaded in the accumulator layout right after the front half), so the block's output IS the accumulator and the epilogue
+// neither reads nor multiplies.  profiles/r04_convnext_residual_in_accumulators.txt: fabric traffic 278.5 -> 267.4 MB per launch
+// only (the epilogue's second read of x was served by L2 already; the rest of the "2.0 x" is the weight stream fetched once per
+// XCD and the halo rows), block 261.9 -> 263.2 us, MLP-only form 243.2 -> 251.2 us (48 strided loads per lane exposed behind the
+// front half), whole step 20.42 -> 20.44 ms.
+#ifndef CX_RES_ACC
+#define CX_RES_ACC 0
+#endif
 
 __device__ __forceinline__ void cx_glds16(const void* gsrc, unsigned lds_addr) {
     unsigned keep;
@@ -289,12 +299,37 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
     for (int i = 0; i < CX_PF; ++i) ring[i] = wfrag(i);
 
     f32x16 acc2[4][4];  // [n block of this wave][frame block]
+#if CX_RES_ACC
+    // the accumulators start at the residual stream + gamma * b2: register r = 4 g + e of tile (n, b) in lane (lf, lh) is frame
+    // 32 b + lf, column 128 w + 32 n + 8 g + 4 lh + e.  One scheduling region per column block: 16 strided 16-byte loads each
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int col = 128 * w + 32 * a + 8 * g + 4 * lh;
+            const float4 gv = *reinterpret_cast<const float4*>(gamma + col);
+            const float4 bv = *reinterpret_cast<const float4*>(b2 + col);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long row = (long)row0 + 32 * b + lf;
+                const float4 xv = row < M ? *reinterpret_cast<const float4*>(x + row * CX_C + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc2[a][b][4 * g] = fmaf(gv.x, bv.x, xv.x); acc2[a][b][4 * g + 1] = fmaf(gv.y, bv.y, xv.y);
+                acc2[a][b][4 * g + 2] = fmaf(gv.z, bv.z, xv.z); acc2[a][b][4 * g + 3] = fmaf(gv.w, bv.w, xv.w);
+            }
+        }
+        // the tiles are materialised in AGPRs HERE: left alone, hipcc sinks the adds and the v_accvgpr_writes to the first use
+        // of the accumulators (GEMM2 of the slice loop) and carries the 64 loaded float4 through GEMM1(0) in VGPRs (66 spills)
+        asm volatile("" : "+a"(acc2[a][0]), "+a"(acc2[a][1]), "+a"(acc2[a][2]), "+a"(acc2[a][3]));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[a][b][r] = 0.f;
+#endif
     f32x16 acc1[4];  // [frame block]: H^T tile of this wave's 32 hidden rows
 
     // Every k-step is its own scheduling region (sched_barrier at its end): the step issues the refill of the ring slot it
@@ -424,6 +459,7 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
         return;
     }
     // ---- epilogue: x[row][n] += gamma[n] * (out[row][n] + b2[n]), via a transposed f32 image [64 frames][516]
+    // (CX_RES_ACC: the accumulators hold exactly that already; the rows are only transposed and stored)
     float* tl = reinterpret_cast<float*>(smem);
     float4 g4[2], c4[2];
 #pragma unroll
@@ -433,7 +469,7 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-#if CX_EPI_PREFETCH
+#if CX_EPI_PREFETCH && !CX_RES_ACC
         // the residual rows of this pass first: 32 independent 16-byte loads per lane, in flight across the LDS round trip
         // (the arithmetic registers of the slice loop are free here)
         float4 rr[16][2];
@@ -468,6 +504,9 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const float4 v = *reinterpret_cast<const float4*>(tl + fl * CX_TLD + 256 * hf + 4 * lane);
+#if CX_RES_ACC
+                    const float4 r = v;
+#else
 #if CX_EPI_PREFETCH
                     float4 r = rr[i][hf];
 #else
@@ -475,6 +514,7 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
 #endif
                     r.x += g4[hf].x * (v.x + c4[hf].x); r.y += g4[hf].y * (v.y + c4[hf].y);
                     r.z += g4[hf].z * (v.z + c4[hf].z); r.w += g4[hf].w * (v.w + c4[hf].w);
+#endif
                     *reinterpret_cast<float4*>(xo + row * CX_C + 256 * hf + 4 * lane) = r;
                 }
             }
@@ -948,8 +988,9 @@ __global__ void convnext16_pack_kernel(const bf16_t* __restrict__ w1, const bf16
 // One thread per 16-byte chunk of the packed stream.  Stream of wave w: for slice j: [GEMM1(j) fragments: W1 rows
 // 128 j + 32 w .. + 31, k-steps s = 0..31], and after GEMM1(j) for j >= 1 (and once more at the end) the GEMM2 fragments
 // of slice j - 1: for k-step q = 0..7, n block 4 w + n, n = 0..3.  Consumption order: G1(0), G1(1), G2(0), G1(2), G2(1), ...
+// gamma (optional): W2 rows are scaled by it before the bf16 rounding (CX_RES_ACC: the kernel then never multiplies by gamma)
 __global__ void convnext_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2, uint4* __restrict__ out,
-                                     int NS) {
+                                     int NS, const float* __restrict__ gamma) {
     const long per_wave = (long)NS * 64 + CX_PF;
     const long total = 4 * per_wave * 64;
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -977,6 +1018,15 @@ __global__ void convnext_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t
             const uint2 lo = *reinterpret_cast<const uint2*>(w2 + nrow * I + hid);
             const uint2 hi = *reinterpret_cast<const uint2*>(w2 + nrow * I + hid + 8);
             v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            if (gamma) {
+                const float gsc = gamma[nrow];
+                unsigned* pv = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = bf16_to_f32((bf16_t)(pv[k] & 0xffffu)) * gsc, b = bf16_to_f32((bf16_t)(pv[k] >> 16)) * gsc;
+                    pv[k] = (unsigned)f32_to_bf16(a) | ((unsigned)f32_to_bf16(b) << 16);
+                }
+            }
         }
     }
     out[id] = v;
@@ -989,20 +1039,21 @@ extern "C" int64_t swc_convnext_stream_bytes(int32_t C, int32_t I) {
     return 4L * ((long)(I / CX_SL) * 64 + CX_PF) * 1024;
 }
 
-extern "C" int swc_convnext_pack(const void* w1, const void* w2, void* stream_out, int32_t C, int32_t I, void* stream) {
-    SWC_CHECK_ARG(w1 && w2 && stream_out, "swc_convnext_pack: null pointer");
+extern "C" int swc_convnext_pack(const void* w1, const void* w2, const float* gamma, void* stream_out, int32_t C, int32_t I,
+                                 void* stream) {
+    SWC_CHECK_ARG(w1 && w2 && gamma && stream_out, "swc_convnext_pack: null pointer");
     SWC_CHECK_ARG(C == CX_C && I > 0 && I % CX_SL == 0, "swc_convnext_pack: needs C = %d and I a multiple of %d (C=%d I=%d)",
                   CX_C, CX_SL, C, I);
     SWC_CHECK_ARG(aligned16(w1) && aligned16(w2) && aligned16(stream_out), "swc_convnext_pack: unaligned");
     const int NS = I / CX_SL;
     const long total = 4L * ((long)NS * 64 + CX_PF) * 64;
 #if CX_MFMA16
-    auto pack = convnext16_pack_kernel;
+    hipLaunchKernelGGL(convnext16_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)w1, (const bf16_t*)w2, (uint4*)stream_out, NS);
 #else
-    auto pack = convnext_pack_kernel;
+    hipLaunchKernelGGL(convnext_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)w1, (const bf16_t*)w2, (uint4*)stream_out, NS, CX_RES_ACC ? gamma : (const float*)nullptr);
 #endif
-    hipLaunchKernelGGL(pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w1,
-                       (const bf16_t*)w2, (uint4*)stream_out, NS);
     SWC_CHECK_LAUNCH("swc_convnext_pack");
     return SWC_OK;
 }

@@ -312,10 +312,12 @@ def convnext_supported(C_, I):
     return _lib.load().swc_convnext_stream_bytes(C_, I) > 0
 
 
-def convnext_pack(w1, w2):
-    """pwconv1.weight [I, C] and pwconv2.weight [C, I] (bf16, device) -> the packed operand stream of swc_convnext_mlp."""
+def convnext_pack(w1, w2, gamma):
+    """pwconv1.weight [I, C], pwconv2.weight [C, I] (bf16, device) and the block's gamma [C] (f32) -> the packed operand stream of
+    swc_convnext_mlp / swc_convnext_block (gamma is folded into pwconv2's rows)."""
     lib = _lib.load()
     _chk(w1, "convnext_pack w1", torch.bfloat16); _chk(w2, "convnext_pack w2", torch.bfloat16)
+    _chk(gamma, "convnext_pack gamma", torch.float32)
     I, C_ = w1.shape
     if tuple(w2.shape) != (C_, I):
         raise _lib.SwcError(f"convnext_pack: w2 is {tuple(w2.shape)}, expected {(C_, I)}")
@@ -323,8 +325,8 @@ def convnext_pack(w1, w2):
     if n <= 0:
         raise _lib.SwcError(f"convnext_pack: unsupported geometry C={C_} I={I}")
     out = torch.empty(n, dtype=torch.uint8, device=w1.device)
-    _lib.check(lib.swc_convnext_pack(_ptr(w1.contiguous()), _ptr(w2.contiguous()), _ptr(out), C_, I, _stream()),
-               "swc_convnext_pack")
+    _lib.check(lib.swc_convnext_pack(_ptr(w1.contiguous()), _ptr(w2.contiguous()), _ptr(gamma.contiguous()), _ptr(out), C_, I,
+                                     _stream()), "swc_convnext_pack")
     return out
 
 

@@ -329,9 +329,11 @@ def test_build_options_still_compile(tmp_path):
     common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-fno-slp-vectorize",
               "-I", os.path.join(root, "include"), "-I", csrc, "-c"]
     jobs = [(["-DCX_MFMA16=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], "swc_convnext.hip"),
+            (["-DCX_RES_ACC=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], "swc_convnext.hip"),
+            (["-DML_ABL=63", "-DML_PF=8", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], "swc_mlp.hip"),
             (["-DATT_ABL=62"], "swc_attention16.hip")]
-    procs = [subprocess.Popen(common + flags + [os.path.join(csrc, src), "-o", str(tmp_path / (src + ".o"))],
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for flags, src in jobs]
+    procs = [subprocess.Popen(common + flags + [os.path.join(csrc, src), "-o", str(tmp_path / (f"{i}_{src}.o"))],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i, (flags, src) in enumerate(jobs)]
     for (flags, src), p in zip(jobs, procs):
         out, _ = p.communicate(timeout=600)
         assert p.returncode == 0, f"{src} {flags}:\n{out[-2000:]}"

@@ -716,7 +716,7 @@ def test_convnext_mlp_fused(M, I):
     h = F.gelu(y.double() @ w1.double().T + b1.double())
     ref = x0.double() + gam.double() * (h @ w2.double().T + b2.double())
     yd, w1d, w2d = y.to(DEV), w1.to(DEV), w2.to(DEV)
-    ws = ops.convnext_pack(w1d, w2d)
+    ws = ops.convnext_pack(w1d, w2d, gam.to(DEV))
     x = x0.to(DEV).clone()
     ops.convnext_mlp(yd, ws, b1.to(DEV), b2.to(DEV), gam.to(DEV), x, M=M, C_=C, I=I)
     # the two-GEMM path
@@ -748,7 +748,7 @@ def test_convnext_block_fused(B, T, I):
     w2 = (torch.randn(C, I, generator=g) * I ** -0.5).to(torch.bfloat16)
     b1, b2, gam = torch.randn(I, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g)
     d = lambda t: t.to(DEV)
-    ws = ops.convnext_pack(d(w1), d(w2))
+    ws = ops.convnext_pack(d(w1), d(w2), d(gam))
     xd = d(x0)
     out = torch.full_like(xd, float("nan"))
     ops.convnext_block(xd, out, d(w7), d(db), d(lw), d(lb), 1e-6, ws, d(b1), d(b2), d(gam), B=B, T=T, C_=C, I=I)

@@ -15,7 +15,7 @@ xs = [torch.randn(M, C, device=dev, generator=g) for _ in range(NB)]
 w1 = (torch.randn(I, C, device=dev, generator=g) * C ** -0.5).to(torch.bfloat16)
 w2 = (torch.randn(C, I, device=dev, generator=g) * I ** -0.5).to(torch.bfloat16)
 b1, b2, gam = torch.randn(I, device=dev) * 0.1, torch.randn(C, device=dev) * 0.1, torch.randn(C, device=dev) * 0.1
-ws = ops.convnext_pack(w1, w2)
+ws = ops.convnext_pack(w1, w2, gam)
 hh = torch.empty(M, I, device=dev, dtype=torch.bfloat16)
 
 
