@@ -143,9 +143,17 @@ def test_flac_crafted_header_cannot_demand_memory(tmp_path, monkeypatch):
     biggest = []
     real_empty = np.empty
     monkeypatch.setattr(np, "empty", lambda shape, *a, **k: (biggest.append(int(np.prod(shape))), real_empty(shape, *a, **k))[1])
+    with pytest.raises(ValueError, match="ceiling"):
+        wavio._decode_flac(str(p))
+    assert not biggest                                            # beyond the decoder's hard ceiling (2^31 samples): refused before any allocation
+    # a declared count UNDER the ceiling (2^30 samples, 4 GiB if believed) that the stream does not hold: buffers are sized by the
+    # file and grow a few steps, the decode fails because the stream ends early
+    raw[q + 13] &= 0xF0
+    raw[q + 14:q + 18] = (1 << 30).to_bytes(4, "big")
+    p.write_bytes(bytes(raw))
     with pytest.raises(ValueError):
         wavio._decode_flac(str(p))
-    assert max(biggest) <= 64 * (16 * len(raw) + 65536)          # a few growth steps from the file-size guess, never 2^36
+    assert biggest and max(biggest) <= 64 * (16 * len(raw) + 65536)   # a few growth steps from the file-size guess, never 2^30
     biggest.clear()
     z = np.zeros((3_000_000, 1), dtype=np.int64)                 # 3 M samples of silence in a few hundred bytes
     pz = tmp_path / "silence.flac"
