@@ -548,8 +548,9 @@ class AudioCodec(nn.Module):
                 L.w2, L.b2 = W(sd[p + "fc2.weight"], dt), V(sd[p + "fc2.bias"])
                 # the fused MLP sub-block kernel (swc_mlp_block) exists for the shipped geometry with bf16 operands
                 ok = (dt == torch.bfloat16 and fc1_dt in (None, dt) and ops.mlp_supported(L.w1.w.shape[1], L.w1.w.shape[0]))
-                L.ws = ops.mlp_pack(L.w1.w, L.w2.w) if ok else None
-                L.wts = ops.layer_tail_pack(L.wo.w, L.w1.w, L.w2.w) if ok else None
+                # (one stream per layer and form, ~10 MB each: only the form `layer_fusion` selects at pack time is built)
+                L.ws = ops.mlp_pack(L.w1.w, L.w2.w) if ok and self.layer_fusion == 1 else None
+                L.wts = ops.layer_tail_pack(L.wo.w, L.w1.w, L.w2.w) if ok and self.layer_fusion >= 2 else None
                 out.append(L)
             return out
 
@@ -710,7 +711,7 @@ class AudioCodec(nn.Module):
                 _, x = ops.layer_tail(a, h, L.wts, L.bo, L.ln2[0], L.ln2[1], 1e-5, L.b1, L.b2, M=M, D=D, F=F_, next_ln=nxt)
                 continue
             self._mm(a, L.wo, M, D, D, lda=D, bias=L.bo, residual=h, out=h)
-            if fused:
+            if fused and self.layer_fusion == 1:
                 _, x = ops.mlp_block(h, L.ln2[0], L.ln2[1], 1e-5, L.ws, L.b1, L.b2, M=M, D=D, F=F_, next_ln=nxt)
                 continue
             dt1 = L.w1.w.dtype if L.w1.w.dtype == ops.FP8_T else dt  # (preset fp8_fc1: fc1 alone reads e4m3 rows, writes bf16)
@@ -724,12 +725,13 @@ class AudioCodec(nn.Module):
     # CUs the two-GEMM form, whose 64/128-row tiles of N = 3072 spread over more CUs, is faster)
     fused_layer_mlp_min_rows = 64 * 160
     layer_fusion = 2  # 2: swc_layer_tail (out-proj + MLP sub-block in one kernel); 1: swc_mlp_block behind an out-proj GEMM; 0: off
+    #                   (read at pack time for the operand streams: set it before the first call, or drop `_pk` to re-pack)
 
     def _mlp_fused(self, layers, M, dt):
         if dt != torch.bfloat16 or M < self.fused_layer_mlp_min_rows or self.layer_fusion <= 0:
             return False
-        if any(getattr(L, "ws", None) is None for L in layers):
-            return False
+        if any(getattr(L, "wts" if self.layer_fusion >= 2 else "ws", None) is None for L in layers):
+            return False  # (operands packed for another `layer_fusion`, an older packed file, another geometry: the unfused layers)
         if self.fused_layer_mlp_min_rows <= 0:  # forced (tests run the kernel on the few-second fixtures)
             return True
         tiles = spec.cdiv(M, 64)

@@ -945,4 +945,9 @@ def test_layer_tail_fused(M, F_, with_next):
         assert torch.equal(yn, want)     # LayerNorm_next of the kernel's own x_out: the arithmetic of swc_layernorm
     else:
         assert yn is None
+    # out of place: the input stream is read only, the result is the same bits
+    xin, out = d(x0).clone(), torch.full((M, D), float("nan"), device=DEV)
+    ops.layer_tail(d(att), xin, wts, d(bo), d(lw), d(lb), 1e-5, d(b1), d(b2), M=M, D=D, F=F_, x_out=out,
+                   next_ln=(d(nw), d(nb)) if with_next else None)
+    assert torch.equal(xin.cpu(), x0) and torch.equal(out, xo)
 

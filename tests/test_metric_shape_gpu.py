@@ -85,12 +85,16 @@ def test_stage_decoder_fused_mlp_kernel(name, fusion):
     keep, keep_f = m.fused_layer_mlp_min_rows, m.layer_fusion
     try:
         m.fused_layer_mlp_min_rows, m.layer_fusion = 0, fusion
+        if fusion != keep_f:
+            m._pk = None   # the operand streams are packed for one form (read at pack time)
         with torch.cuda.device(0), torch.inference_mode(), _Spy("mlp_block") as spy1, _Spy("layer_tail") as spy2, \
                 _Spy("layernorm") as ln:
             P = m._packed()
             mel = m._decoder(up.reshape(B * Tt, D).clone(), lat, B, Tt, P).float().cpu().numpy()
     finally:
         m.fused_layer_mlp_min_rows, m.layer_fusion = keep, keep_f
+        if fusion != keep_f:
+            m._pk = None
     assert (spy1.calls, spy2.calls) == ((0, 12) if fusion == 2 else (12, 0)) and len(P.dec_layers) == 12
     assert ln.calls == 2   # the first layer's self_attn_layer_norm and the decoder's final LayerNorm; 24 are folded away
     e = _relerr(mel, g["st_dec_mel"].transpose(0, 2, 1))

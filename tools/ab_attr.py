@@ -46,8 +46,14 @@ def timed(fn, n=10):
 
 
 outs, res = {}, {v: {"encode": [], "decode": [], "step": []} for v in vals}
-for v in vals:
+def setv(v):
     setattr(m, a.attr, v)
+    if a.attr in ("layer_fusion", "conv1_split_f16"):   # read at pack time: re-pack
+        m._pk = None
+
+
+for v in vals:
+    setv(v)
     for _ in range(3):
         c = m.encode(wavs)["codes_list"]; w = m.decode(c)["syn_wav_list"]
     outs[v] = (torch.stack([x.long() for x in c]), torch.stack(list(w)))
@@ -58,7 +64,7 @@ for v in vals[1:]:
           f"{float((w0 - w1).abs().max() / w0.abs().max()):.3e}")
 for r in range(a.rounds):
     for v in vals:
-        setattr(m, a.attr, v)
+        setv(v)
         c = m.encode(wavs)["codes_list"]
         res[v]["encode"].append(timed(lambda: m.encode(wavs)))
         res[v]["decode"].append(timed(lambda: m.decode(c)))
