@@ -279,7 +279,9 @@ class AudioCodec(nn.Module):
             # (not inference tensors, whatever the caller's mode: saturation_count() updates the host copy in place later)
             with torch.inference_mode(False):
                 st = {"dev": dev, "buf": torch.zeros(2, dtype=torch.int32, device=dev),
-                      "host": torch.zeros(2, dtype=torch.int32).pin_memory(), "seen": [0, 0], "warned": False}
+                      "host": torch.zeros(2, dtype=torch.int32).pin_memory(),
+                      "snap": torch.zeros(2, dtype=torch.int32).pin_memory(), "snap_ev": None,
+                      "seen": [0, 0], "warned": False}
             self.__dict__["_sat"] = st
         return st
 
@@ -295,9 +297,21 @@ class AudioCodec(nn.Module):
         n = st["host"].tolist()
         return {"f16s": int(n[0]), "fp8": int(n[1])}
 
+    def _snapshot_counters(self):
+        """enqueue a copy of the clip counters into pinned memory behind the kernels enqueued so far, with an event: the
+        deferred check later waits for THAT point of the stream only, not for what was enqueued after it"""
+        st = self._sat_state(self._buffers_device())
+        with torch.cuda.device(st["dev"]), torch.inference_mode(False):
+            st["snap"].copy_(st["buf"], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        st["snap_ev"] = ev
+
     class _Deferred:
         """`with model.deferred_range_check() as chk:` — inside, encode-side calls do not read the clip counters back (no
-        stream synchronisation between encode and the work enqueued after it); leaving the block reads them once.
+        stream synchronisation between encode and the work enqueued after it); leaving the block reads them once — from a
+        snapshot taken right behind the encode kernels (round 4): the host waits for the encode part of the block only and
+        returns while the decode it enqueued afterwards is still running, so the next call's host work overlaps it.
         chk.clipped is then True when split-f16 operands clipped: with policy "fallback" the model has switched to exact-f32
         encoder operands and THE CALLER MUST REDO the block (its codes are not reliable); "raise" raises here."""
 
@@ -311,19 +325,24 @@ class AudioCodec(nn.Module):
         def __exit__(self, et, ev, tb):
             self.m.__dict__["_defer"] -= 1
             if et is None and self.m.__dict__["_defer"] == 0 and self.m.__dict__.pop("_defer_pending", False):
-                self.clipped = self.m._check_clipping(self.m.__dict__.pop("_defer_ran_as", None))
+                self.clipped = self.m._check_clipping(self.m.__dict__.pop("_defer_ran_as", None), snapshot=True)
             return False
 
     def deferred_range_check(self):
         return AudioCodec._Deferred(self)
 
-    def _check_clipping(self, ran_as=None):
-        """Read the counters (synchronises), apply the policy.  True: split-f16 operands clipped since the last check and the
+    def _check_clipping(self, ran_as=None, snapshot=False):
+        """Read the counters (synchronises; snapshot: waits for the event of the last _snapshot_counters() only), apply the policy.  True: split-f16 operands clipped since the last check and the
         model switched to exact-f32 encoder operands (policy "fallback"): the caller re-runs.  ran_as: the preset the checked
         kernels ran with (with batches in flight another thread may have switched this model's preset meanwhile)."""
         e = PRECISIONS[ran_as or self._precision][0]
         st = self._sat_state(self._buffers_device())
-        n = self.saturation_count()
+        if snapshot and st["snap_ev"] is not None:
+            st["snap_ev"].synchronize()
+            v = st["snap"].tolist()
+            n, st["snap_ev"] = {"f16s": int(v[0]), "fp8": int(v[1])}, None
+        else:
+            n = self.saturation_count()
         new16, new8 = n["f16s"] - st["seen"][0], n["fp8"] - st["seen"][1]
         st["seen"] = [n["f16s"], n["fp8"]]
         if new8 and not st["warned"]:
@@ -387,6 +406,7 @@ class AudioCodec(nn.Module):
         if self.__dict__.get("_defer", 0) > 0:  # inside deferred_range_check(): one read-back when the block ends
             self.__dict__["_defer_pending"] = True
             self.__dict__["_defer_ran_as"] = ran_as
+            self._snapshot_counters()   # (counters are cumulative: the last snapshot of the block covers every encode in it)
             return out
         if self._check_clipping(ran_as):
             with AudioCodec._REPACK_LOCK:

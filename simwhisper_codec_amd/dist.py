@@ -20,6 +20,8 @@ batch loop (inference.py:38-64) for batches larger than one GPU's share.
     length and sharded results equal the single-GPU batch bit for bit.
   * encode_decode(): the gather of the codes (tiny) is posted before the local decode starts and completes under it.
 """
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -115,9 +117,14 @@ class DataParallelCodec:
         failed, EVERY rank raises here — the failing one its own exception, the others a RuntimeError naming the situation —
         before another collective or point-to-point call is posted."""
         if self.world > 1:
-            t = torch.tensor([0 if error is not None else 1], dtype=torch.int64, device=self.comm)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
-            ok = int(t.item()) == 1
+            # the flag is known on the HOST once the local work is enqueued; on RCCL the all-reduce runs from a side stream so
+            # that reading it back waits for the peers, not for this rank's own decode kernels (round 4: the step no longer ends
+            # in a drain of the compute stream; the gathers posted next are stream-ordered behind the decode as before)
+            side = self._status_stream()
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                t = torch.tensor([0 if error is not None else 1], dtype=torch.int64, device=self.comm)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+                ok = int(t.item()) == 1
         else:
             ok = error is None
         if error is not None:
@@ -125,6 +132,14 @@ class DataParallelCodec:
         if not ok:
             raise RuntimeError("DataParallelCodec: another rank failed in its local encode / decode; this step is abandoned "
                                "on every rank")
+
+    def _status_stream(self):
+        if self.comm.type != "cuda":
+            return None
+        st = self.__dict__.get("_side")
+        if st is None:
+            st = self.__dict__["_side"] = torch.cuda.Stream(device=self.comm)
+        return st
 
     def _guarded(self, fn):
         """fn() = this rank's local work; returns its result after all ranks have agreed that nobody failed.  Rank 0's
