@@ -54,7 +54,7 @@ import yaml  # noqa: E402
 # MI355X dense MFMA peaks (MI355X_MICROARCH.md).  gemm_f16s executes 3 f16 MFMA passes per algorithmic multiply-add
 # (hi*hi + hi*lo + lo*hi), so its ceiling in algorithmic FLOP/s is 2500 / 3.  gemm_fp8 runs on the block-scaled
 # v_mfma_scale_f32_16x16x128_f8f6f4 (2x the bf16 rate).
-PEAK_TFLOPS = {"gemm_bf16": 2500.0, "convnext_bf16": 2500.0, "mlp_bf16": 2500.0, "gemm_f32": 157.3,
+PEAK_TFLOPS = {"gemm_bf16": 2500.0, "convnext_bf16": 2500.0, "mlp_bf16": 2500.0, "mlp_fp8fc1": 2500.0, "gemm_f32": 157.3,
                "gemm_f16s": 2500.0 / 3.0, "gemm_fp8": 5000.0}
 
 

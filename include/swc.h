@@ -231,14 +231,19 @@ int swc_mlp_block(const float* x, float* x_out, const float* ln_w, const float* 
  * accumulator layout (row statistics exchanged between the 4 waves through LDS), and the MLP's residual add costs nothing.
  * A decoder layer is then three launches: q/k/v GEMM, attention, this.  Same geometry limits, operand types and GELU as
  * swc_mlp_block; `w_stream` comes from swc_layer_tail_pack(out_proj.weight [D][D], fc1.weight [F][D], fc2.weight [D][F])
- * (swc_layer_tail_stream_bytes(D, F) bytes).  x_out may be x.
+ * (swc_layer_tail_stream_bytes(D, F, fc1_dtype) bytes).  x_out may be x.
+ * fc1_dtype = SWC_FP8 (preset fp8_fc1): fc1 alone runs on the block-scaled fp8 MFMA — fc1.weight is then e4m3 bytes [F][D] at a
+ * per-tensor power-of-two scale sw, the kernel writes LayerNorm(x') to LDS as e4m3 at SWC_FP8_ACT_SCALE (clipping is counted:
+ * swc_set_saturation_counter) and multiplies fc1's accumulators by fc1_alpha = 1 / (SWC_FP8_ACT_SCALE * sw); everything else stays
+ * bf16.  fc1_dtype = SWC_BF16: fc1_alpha is ignored.  The stream must have been packed for the same fc1_dtype.
  */
-int64_t swc_layer_tail_stream_bytes(int32_t D, int32_t F);
-int swc_layer_tail_pack(const void* wo_bf16, const void* w1_bf16, const void* w2_bf16, void* w_stream, int32_t D, int32_t F,
-                        void* stream);
+int64_t swc_layer_tail_stream_bytes(int32_t D, int32_t F, int32_t fc1_dtype);
+int swc_layer_tail_pack(const void* wo_bf16, const void* w1, const void* w2_bf16, void* w_stream, int32_t D, int32_t F,
+                        int32_t fc1_dtype, void* stream);
 int swc_layer_tail(const void* attn, const float* x, float* x_out, const void* w_stream, const float* bo, const float* ln_w,
                    const float* ln_b, float eps, const float* b1, const float* b2, const float* next_ln_w,
-                   const float* next_ln_b, void* y_next, int32_t M, int32_t D, int32_t F, void* stream);
+                   const float* next_ln_b, void* y_next, int32_t M, int32_t D, int32_t F, int32_t fc1_dtype, float fc1_alpha,
+                   void* stream);
 
 /*
  * ConvNeXt front half: depthwise Conv1d(k=7, pad=3, groups=C) + LayerNorm(eps)

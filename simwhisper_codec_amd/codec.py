@@ -567,9 +567,10 @@ class AudioCodec(nn.Module):
                 L.w1, L.b1 = W(sd[p + "fc1.weight"], fc1_dt or dt), V(sd[p + "fc1.bias"])
                 L.w2, L.b2 = W(sd[p + "fc2.weight"], dt), V(sd[p + "fc2.bias"])
                 # the fused MLP sub-block kernel (swc_mlp_block) exists for the shipped geometry with bf16 operands
-                ok = (dt == torch.bfloat16 and fc1_dt in (None, dt) and ops.mlp_supported(L.w1.w.shape[1], L.w1.w.shape[0]))
+                ok = dt == torch.bfloat16 and ops.mlp_supported(L.w1.w.shape[1], L.w1.w.shape[0])
+                f8fc1 = fc1_dt == ops.FP8_T   # (preset fp8_fc1: swc_layer_tail runs fc1 on the fp8 MFMA; swc_mlp_block is bf16 only)
                 # (one stream per layer and form, ~10 MB each: only the form `layer_fusion` selects at pack time is built)
-                L.ws = ops.mlp_pack(L.w1.w, L.w2.w) if ok and self.layer_fusion == 1 else None
+                L.ws = ops.mlp_pack(L.w1.w, L.w2.w) if ok and not f8fc1 and self.layer_fusion == 1 else None
                 L.wts = ops.layer_tail_pack(L.wo.w, L.w1.w, L.w2.w) if ok and self.layer_fusion >= 2 else None
                 out.append(L)
             return out
@@ -728,7 +729,8 @@ class AudioCodec(nn.Module):
             nxt = layers[i + 1].ln1 if i + 1 < len(layers) else None
             if fused and self.layer_fusion >= 2 and getattr(L, "wts", None) is not None:
                 # out-proj + residual + LayerNorm + MLP + residual + next LayerNorm: one kernel
-                _, x = ops.layer_tail(a, h, L.wts, L.bo, L.ln2[0], L.ln2[1], 1e-5, L.b1, L.b2, M=M, D=D, F=F_, next_ln=nxt)
+                _, x = ops.layer_tail(a, h, L.wts, L.bo, L.ln2[0], L.ln2[1], 1e-5, L.b1, L.b2, M=M, D=D, F=F_, next_ln=nxt,
+                                      fc1_dtype=L.w1.w.dtype, fc1_alpha=L.w1.alpha)
                 continue
             self._mm(a, L.wo, M, D, D, lda=D, bias=L.bo, residual=h, out=h)
             if fused and self.layer_fusion == 1:

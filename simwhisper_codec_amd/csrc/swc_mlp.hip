@@ -83,6 +83,20 @@ __device__ __forceinline__ void ml_mfma2x2_vgpr(const u32x4& a0, const u32x4& a1
         : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
 }
 
+// fp8 fc1: one W1 fragment (16 hidden x 128 k, e4m3) against the four token tiles, accumulators in VGPRs (given the builtin, hipcc
+// puts these 64 accumulators — and even operands — into AGPRs beside GEMM2's 192 and shuffles: 776 v_accvgpr_* and 250 spills).
+// Scales: one VGPR holding 0x7f7f7f7f (E8M0 2^0 for every 32-block; the tensor scales live in alpha1); cbsz / blgp 0 = e4m3.
+__device__ __forceinline__ void ml_mfma8_1x4_vgpr(const i32x8& a, const i32x8& b0, const i32x8& b1, const i32x8& b2, const i32x8& b3,
+                                                  f32x4& c0, f32x4& c1, f32x4& c2, f32x4& c3, unsigned sc) {
+    asm("s_nop 1\n\t"
+        "v_mfma_scale_f32_16x16x128_f8f6f4 %0, %4, %5, %0, %9, %9 op_sel_hi:[0,0,0]\n\t"
+        "v_mfma_scale_f32_16x16x128_f8f6f4 %1, %4, %6, %1, %9, %9 op_sel_hi:[0,0,0]\n\t"
+        "v_mfma_scale_f32_16x16x128_f8f6f4 %2, %4, %7, %2, %9, %9 op_sel_hi:[0,0,0]\n\t"
+        "v_mfma_scale_f32_16x16x128_f8f6f4 %3, %4, %8, %3, %9, %9 op_sel_hi:[0,0,0]"
+        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+        : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(sc));
+}
+
 __device__ __forceinline__ f32x16 ml_mfma32(const u32x4& a, const u32x4& b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b),
                                                    c, 0, 0, 0);
@@ -114,12 +128,21 @@ static_assert(ML_P0 % ML_PF == 0, "the ring index of a fragment must not depend 
 // registers that later accumulate fc2 (so x' never exists in memory and the residual add of the MLP is free), LayerNorm(x')
 // is taken in that transposed layout (row statistics across the 4 waves through LDS) and its bf16 fragments replace the
 // attention tile in LDS.
-template <bool OPROJ>
+// F8 (with OPROJ; preset fp8_fc1): fc1 alone runs on the block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, e4m3 x e4m3,
+// K = 128 per instruction at twice the bf16 rate per clock).  LayerNorm(x') is written to LDS as e4m3 at SWC_FP8_ACT_SCALE
+// (48 KiB instead of 96: B fragments of 128 channels x 16 tokens, 32 bytes per lane as two lane-linear halves), W1 comes from the
+// stream as e4m3 at its per-tensor power-of-two scale (half the bytes per slice), the 16 x 16 accumulator tiles get
+// alpha1 = 1 / (act scale x weight scale), bias and GELU and are written to the H buffer in the 32 x 32 x 16 B-fragment layout
+// (8 bytes per lane: 4 consecutive hidden values of one token), where fc2 reads them as before — in bf16, natural k order.
+template <bool OPROJ, bool F8 = false>
 __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float* xo, MlNorm ln, float eps,
                                                            const u32x4* __restrict__ wstream, const float* __restrict__ b1,
                                                            const float* __restrict__ b2, MlNorm nln,
                                                            bf16_t* __restrict__ y_next, int M, int NS,
-                                                           const bf16_t* __restrict__ att, const float* __restrict__ bo) {
+                                                           const bf16_t* __restrict__ att, const float* __restrict__ bo,
+                                                           float alpha1, unsigned* sat) {
+    static_assert(!F8 || OPROJ, "the fp8 fc1 exists for the layer-tail form");
+    constexpr int G1F = F8 ? ML_FPP / 2 : ML_FPP;  // 1 KiB stream entries of one GEMM1 phase (e4m3: half the bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -129,10 +152,10 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
 
     // ---- weight stream of this wave: wave-uniform byte pointer (SGPR pair, advanced once per phase) + one 32-bit lane
     // offset + immediate
-    const long per_wave = (OPROJ ? ML_P0 : 0) + (long)NS * (2 * ML_FPP) + ML_PF;  // fragments
+    const long per_wave = (OPROJ ? ML_P0 : 0) + (long)NS * (G1F + ML_FPP) + ML_PF;  // fragments
     const char* wbase = reinterpret_cast<const char*>(wstream) + (long)w * per_wave * 1024;
     const unsigned lane_off = (unsigned)lane * 16u;
-    auto wfrag = [&](int i) -> u32x4 {  // fragment i of the current phase (i may run ML_PF past its end)
+    auto wfrag = [&](int i) __attribute__((always_inline)) -> u32x4 {  // fragment i of the current phase (i may run ML_PF past its end)
         if (ML_ABL & 4) i &= ML_PF - 1;
         return *reinterpret_cast<const u32x4*>(wbase + (long)i * 1024 + lane_off);
     };
@@ -315,6 +338,8 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
         }
         // (5) y = LayerNorm(x') as bf16 B fragments over the attention image: registers 8 t .. 8 t + 7 of tile (n, fb), rows
         // pairwise converted, are the fragment of k-step 12 w + 2 n + t (W1 is packed in that channel order)
+        float amax8 = 0.f;
+        (void)amax8;
 #pragma unroll
         for (int n = 0; n < ML_NB; ++n) {
             float4 gw[4], gb[4];
@@ -334,10 +359,26 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
                         o[e] = (acc2[n][fb][r] - mean[fb]) * rstd[fb] * reinterpret_cast<const float*>(&gw[r >> 2])[r & 3] +
                                reinterpret_cast<const float*>(&gb[r >> 2])[r & 3];
                     }
-                    *reinterpret_cast<u32x4*>(smem + (2 * (12 * w + 2 * n + t) + fb) * ML_YP + lane * 16) =
-                        (u32x4){bf16_pack2(o[0], o[1]), bf16_pack2(o[2], o[3]), bf16_pack2(o[4], o[5]), bf16_pack2(o[6], o[7])};
+                    if constexpr (F8) {
+                        // e4m3 at the activation scale, B fragments of the 16 x 16 x 128 MFMA: fragment (s = c / 128, tb = token / 16)
+                        // = 2 KiB as two lane-linear halves; lane' = 16 ((c % 128) / 32) + token % 16 holds 32 channels
+#pragma unroll
+                        for (int hq = 0; hq < 2; ++hq) {
+                            const int c = 192 * w + 32 * n + 8 * (2 * t + hq) + 4 * lh;
+                            const int tok = 32 * fb + lf;
+                            const int off = (((c >> 7) * 4 + (tok >> 4)) * 2 + ((c & 31) >> 4)) * 1024 +
+                                            (16 * ((c & 127) >> 5) + (tok & 15)) * 16 + (c & 15);
+                            *reinterpret_cast<unsigned*>(smem + off) =
+                                fp8_pack4(o[4 * hq] * SWC_FP8_ACT_SCALE, o[4 * hq + 1] * SWC_FP8_ACT_SCALE, o[4 * hq + 2] * SWC_FP8_ACT_SCALE,
+                                          o[4 * hq + 3] * SWC_FP8_ACT_SCALE, amax8);
+                        }
+                    } else {
+                        *reinterpret_cast<u32x4*>(smem + (2 * (12 * w + 2 * n + t) + fb) * ML_YP + lane * 16) =
+                            (u32x4){bf16_pack2(o[0], o[1]), bf16_pack2(o[2], o[3]), bf16_pack2(o[4], o[5]), bf16_pack2(o[6], o[7])};
+                    }
                 }
         }
+        if constexpr (F8) sat_commit(sat, 1, amax8, SWC_FP8_LIMIT);
         __syncthreads();
     }
     f32x16 acc1[2][2];  // [hidden block][token block]: H^T of this wave's 64 hidden rows
@@ -350,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
     // b1 of this wave's 64 hidden rows, one slice ahead: register r = 4 g + e of a lane in half lh belongs to row
     // 8 g + 4 lh + e of its 32-row block
     float4 bias_nx[2][4];
-    auto load_bias = [&](int j) {
+    auto load_bias = [&](int j) __attribute__((always_inline)) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
@@ -360,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
     load_bias(0);
     // Every k-step is its own scheduling region (sched_barrier at its end): it issues the LDS reads of the NEXT step's B
     // fragments, its MFMAs and the refill of the ring slots it consumed (see swc_convnext.hip for what hipcc does otherwise)
-    auto gemm1 = [&](int j) {
+    auto gemm1 = [&](int j) __attribute__((always_inline)) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
@@ -396,14 +437,14 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
     };
     // GELU of accumulator registers 8 t + 4 h .. + 3 of tile (hb, b) -> two packed dwords of B fragment t, kept IN PLACE:
     // they replace registers 4 t + 2 h, + 1 of the same tile (already consumed when the halves run in order)
-    auto gelu_half = [&](int hb, int b, int t, int h) {
+    auto gelu_half = [&](int hb, int b, int t, int h) __attribute__((always_inline)) {
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (ML_ABL & 2) ? acc1[hb][b][8 * t + 4 * h + e] : gelu_fast(acc1[hb][b][8 * t + 4 * h + e]);
 #pragma unroll
         for (int i = 0; i < 2; ++i) acc1[hb][b][4 * t + 2 * h + i] = __uint_as_float(ml_pack_bf16x2(v[2 * i], v[2 * i + 1]));
     };
-    auto store_h = [&]() {
+    auto store_h = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
@@ -416,7 +457,80 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
     };
     // GEMM2 over the slice whose H^T is in LDS; `with_gelu`: the GELU of the NEXT slice (acc1) rides along, half a
     // fragment per k-step, in the same scheduling region as that step's 12 MFMAs
-    auto gemm2 = [&](auto with_gelu) {
+    // ---- fp8 fc1 (F8): GEMM1 on the block-scaled MFMA.  Wave w: 4 hidden tiles of 16 x 4 token tiles of 16, 6 k-steps of 128
+    f32x4 a8[4][4];   // [hidden tile][token tile]: lane (tok = l & 15, g4 = l >> 4) holds hidden rows 16 ht + 4 g4 + r, r = 0..3
+    float4 bias8[4];  // b1 of those rows, loaded at the start of GEMM1(j), consumed by the GELU that rides on GEMM2(j - 1)
+    auto gemm1_f8 = [&](int j) __attribute__((always_inline)) {
+        if constexpr (F8) {
+            const int g4 = lane >> 4;
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) {
+                bias8[ht] = *reinterpret_cast<const float4*>(b1 + (long)j * ML_SL + 64 * w + 16 * ht + 4 * g4);
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) a8[ht][tb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            const u32x4* y8 = reinterpret_cast<const u32x4*>(smem) + lane;
+            auto yfr = [&](int s_, i32x8 (&dst)[4]) {
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) {
+                    const u32x4 lo = y8[((s_ * 4 + tb) * 2) * 64], hi = y8[((s_ * 4 + tb) * 2 + 1) * 64];
+                    dst[tb] = (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                }
+            };
+            i32x8 yA[4], yB[4];
+            yfr(0, yA);
+            auto step8 = [&](int s_, i32x8 (&cur)[4], i32x8 (&nxt)[4]) {
+                if (s_ + 1 < ML_D / 128) yfr(s_ + 1, nxt);
+#pragma unroll
+                for (int ht = 0; ht < 4; ++ht) {
+                    const u32x4 lo = ring[(8 * s_ + 2 * ht) % ML_PF], hi = ring[(8 * s_ + 2 * ht + 1) % ML_PF];
+                    const i32x8 wa = (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+                    ml_mfma8_1x4_vgpr(wa, cur[0], cur[1], cur[2], cur[3], a8[ht][0], a8[ht][1], a8[ht][2], a8[ht][3], 0x7f7f7f7fu);
+                    ring[(8 * s_ + 2 * ht) % ML_PF] = wfrag(8 * s_ + 2 * ht + ML_PF);
+                    ring[(8 * s_ + 2 * ht + 1) % ML_PF] = wfrag(8 * s_ + 2 * ht + 1 + ML_PF);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+#pragma unroll
+            for (int s_ = 0; s_ < ML_D / 128; s_ += 2) {
+                step8(s_, yA, yB);
+                step8(s_ + 1, yB, yA);
+            }
+            // MFMA results in VGPRs -> VALU readers: the wait states hipcc would insert for its own MFMAs
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a8[ht][0]), "+v"(a8[ht][1]), "+v"(a8[ht][2]), "+v"(a8[ht][3]));
+            wbase += G1F * 1024;
+        }
+    };
+    // bias + GELU of one 16 x 16 tile -> two packed dwords (4 bf16), kept in place of the tile's first two registers
+    auto gelu_tile8 = [&](int q) __attribute__((always_inline)) {
+        if constexpr (F8) {
+            const int ht = q >> 2, tb = q & 3;
+            const float* bb = reinterpret_cast<const float*>(&bias8[ht]);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_fast(fmaf(a8[ht][tb][r], alpha1, bb[r]));
+            a8[ht][tb][0] = __uint_as_float(bf16_pack2(v[0], v[1]));
+            a8[ht][tb][1] = __uint_as_float(bf16_pack2(v[2], v[3]));
+        }
+    };
+    // H^T -> the LDS exchange buffer in the B-fragment layout of GEMM2 (32 x 32 x 16): k-step q = 4 w + ht, token block fb,
+    // lane' = 32 (hidden % 16 / 8) + token % 32, 4 consecutive hidden values = 8 bytes
+    auto store_h8 = [&]() __attribute__((always_inline)) {
+        if constexpr (F8) {
+            const int g4 = lane >> 4, tok = lane & 15;
+#pragma unroll
+            for (int ht = 0; ht < 4; ++ht)
+#pragma unroll
+                for (int tb = 0; tb < 4; ++tb) {
+                    const int off = ((4 * w + ht) * 2 + (tb >> 1)) * 1024 + (32 * (g4 >> 1) + 16 * (tb & 1) + tok) * 16 + 8 * (g4 & 1);
+                    *reinterpret_cast<uint2*>(smem + ML_Y_BYTES + off) =
+                        make_uint2(__float_as_uint(a8[ht][tb][0]), __float_as_uint(a8[ht][tb][1]));
+                }
+        }
+    };
+
+    auto gemm2 = [&](auto with_gelu) __attribute__((always_inline)) {
         u32x4 hA[2], hB[2];
         h_frags(0, hA);
         auto step = [&](int q, u32x4 (&cur)[2], u32x4 (&nxt)[2]) {
@@ -427,7 +541,10 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
                 for (int b = 0; b < 2; ++b) acc2[n][b] = ml_mfma32(ring[(q * ML_NB + n) % ML_PF], cur[b], acc2[n][b]);
                 ring[(q * ML_NB + n) % ML_PF] = wfrag(q * ML_NB + n + ML_PF);
             }
-            if constexpr (decltype(with_gelu)::value) gelu_half(q >> 3, (q >> 2) & 1, (q >> 1) & 1, q & 1);
+            if constexpr (decltype(with_gelu)::value) {
+                if constexpr (F8) gelu_tile8(q);
+                else gelu_half(q >> 3, (q >> 2) & 1, (q >> 1) & 1, q & 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
 #pragma unroll
@@ -439,16 +556,27 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
     };
 
     // ---- pipeline over the hidden slices
-    gemm1(0);
+    auto g1 = [&](int j) __attribute__((always_inline)) {
+        if constexpr (F8) gemm1_f8(j);
+        else gemm1(j);
+    };
+    auto sh = [&]() __attribute__((always_inline)) {
+        if constexpr (F8) store_h8();
+        else store_h();
+    };
+    g1(0);
 #pragma unroll
-    for (int q = 0; q < ML_KS2; ++q) gelu_half(q >> 3, (q >> 2) & 1, (q >> 1) & 1, q & 1);
-    store_h();
+    for (int q = 0; q < ML_KS2; ++q) {
+        if constexpr (F8) gelu_tile8(q);
+        else gelu_half(q >> 3, (q >> 2) & 1, (q >> 1) & 1, q & 1);
+    }
+    sh();
     __syncthreads();
     for (int j = 1; j < NS; ++j) {
-        gemm1(j);
+        g1(j);
         gemm2(std::true_type{});
         if (!(ML_ABL & 1)) __syncthreads();  // every wave has read H_{j-1}
-        store_h();
+        sh();
         if (!(ML_ABL & 1)) __syncthreads();  // H_j visible
     }
     gemm2(std::false_type{});
@@ -558,10 +686,17 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
 //                      16 s + 4 (lane >> 5) + {0..3, 8..11}
 //   G2(j), fragment i: k-step q = i / 6, column block n = i % 6: W2 rows 192 w + 32 n + (lane & 31), hidden values
 //                      256 j + 16 q + 4 (lane >> 5) + {0..3, 8..11}: the order GEMM1's accumulators convert in place
-__global__ void mlp_pack_kernel(const bf16_t* __restrict__ wo, const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2,
-                                uint4* __restrict__ out, int NS) {
+__global__ void mlp_pack_kernel(const bf16_t* __restrict__ wo, const void* __restrict__ w1v, const bf16_t* __restrict__ w2,
+                                uint4* __restrict__ out, int NS, int f8) {
+    // f8: w1 is e4m3 bytes [F][D]; a GEMM1 phase is then 48 entries: entry i = k-step s = i / 8 (128 columns), hidden tile
+    // ht = (i % 8) / 2 (16 rows), half h = i % 2: W1 rows 256 j + 64 w + 16 ht + (lane & 15), columns 128 s + 32 (lane >> 4) + 16 h
+    // .. + 15; GEMM2's hidden values are in natural order (H is written to LDS fragment by fragment, not converted in place)
+    const bf16_t* w1 = reinterpret_cast<const bf16_t*>(w1v);
+    const unsigned char* w1q = reinterpret_cast<const unsigned char*>(w1v);
     const long p0 = wo ? ML_P0 : 0;
-    const long per_wave = p0 + (long)NS * (2 * ML_FPP) + ML_PF;
+    const int g1f = f8 ? ML_FPP / 2 : ML_FPP;
+    const long per_slice = g1f + ML_FPP;
+    const long per_wave = p0 + (long)NS * per_slice + ML_PF;
     const long total = 4 * per_wave * 64;
     const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
@@ -575,13 +710,25 @@ __global__ void mlp_pack_kernel(const bf16_t* __restrict__ wo, const bf16_t* __r
     if (f < p0) {
         const int s = (int)(f / ML_NB), n = (int)(f % ML_NB);
         v = *reinterpret_cast<const uint4*>(wo + (long)(192 * w + 32 * n + lf) * ML_D + 16 * s + 8 * lh);
-    } else if (f - p0 < (long)NS * (2 * ML_FPP)) {
+    } else if (f - p0 < (long)NS * per_slice) {
         f -= p0;
-        // phase p: 0 -> G1(0); 2k-1 -> G1(k), 2k -> G2(k-1) for k = 1..NS-1; 2NS-1 -> G2(NS-1)
-        const int p = (int)(f / ML_FPP), i = (int)(f % ML_FPP);
-        const bool is_g1 = p == 0 || ((p & 1) && p < 2 * NS - 1);
-        if (is_g1) {
-            const int j = p == 0 ? 0 : (p + 1) >> 1;
+        // consumption order: G1(0), G1(1), G2(0), G1(2), G2(1), ..., G1(NS-1), G2(NS-2), G2(NS-1)
+        int j, i;
+        bool is_g1;
+        if (f < g1f) { is_g1 = true; j = 0; i = (int)f; }
+        else {
+            const long r = f - g1f;                       // pairs (G1(k), G2(k-1)) for k = 1 .. NS-1, then G2(NS-1)
+            const long pair = r / per_slice, o = r % per_slice;
+            if (pair < NS - 1) {
+                if (o < g1f) { is_g1 = true; j = (int)pair + 1; i = (int)o; }
+                else { is_g1 = false; j = (int)pair; i = (int)(o - g1f); }
+            } else { is_g1 = false; j = NS - 1; i = (int)(r - (long)(NS - 1) * per_slice); }
+        }
+        if (is_g1 && f8) {
+            const int s = i >> 3, ht = (i >> 1) & 3, h = i & 1;
+            const long row = (long)j * ML_SL + 64 * w + 16 * ht + (lane & 15);
+            v = *reinterpret_cast<const uint4*>(w1q + row * ML_D + 128 * s + 32 * (lane >> 4) + 16 * h);
+        } else if (is_g1) {
             const int s = i >> 1, hb = i & 1;
             const long row = (long)j * ML_SL + 64 * w + 32 * hb + lf;  // hidden row
             if (wo) {
@@ -592,26 +739,30 @@ __global__ void mlp_pack_kernel(const bf16_t* __restrict__ wo, const bf16_t* __r
                 v = *reinterpret_cast<const uint4*>(w1 + row * ML_D + 16 * s + 8 * lh);
             }
         } else {
-            const int j = p == 2 * NS - 1 ? NS - 1 : (p >> 1) - 1;
             const int q = i / ML_NB, n = i % ML_NB;
             const long nrow = 192 * w + 32 * n + lf;  // output column = row of W2
-            const long hid = (long)j * ML_SL + 16 * q + 4 * lh;  // elements jj: hid + 8 (jj >> 2) + (jj & 3)
-            const uint2 lo = *reinterpret_cast<const uint2*>(w2 + nrow * F + hid);
-            const uint2 hi = *reinterpret_cast<const uint2*>(w2 + nrow * F + hid + 8);
-            v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            if (f8) {
+                v = *reinterpret_cast<const uint4*>(w2 + nrow * F + (long)j * ML_SL + 16 * q + 8 * lh);
+            } else {
+                const long hid = (long)j * ML_SL + 16 * q + 4 * lh;  // elements jj: hid + 8 (jj >> 2) + (jj & 3)
+                const uint2 lo = *reinterpret_cast<const uint2*>(w2 + nrow * F + hid);
+                const uint2 hi = *reinterpret_cast<const uint2*>(w2 + nrow * F + hid + 8);
+                v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
         }
     }
     out[id] = v;
 }
 
-int ml_pack(const void* wo, const void* w1, const void* w2, void* stream_out, int32_t D, int32_t F, void* stream, const char* who) {
+int ml_pack(const void* wo, const void* w1, const void* w2, void* stream_out, int32_t D, int32_t F, void* stream, const char* who,
+            int f8 = 0) {
     SWC_CHECK_ARG(w1 && w2 && stream_out, "%s: null pointer", who);
     SWC_CHECK_ARG(D == ML_D && F > 0 && F % ML_SL == 0, "%s: needs D = %d and F a multiple of %d (D=%d F=%d)", who, ML_D, ML_SL, D, F);
     SWC_CHECK_ARG(aligned16(wo) && aligned16(w1) && aligned16(w2) && aligned16(stream_out), "%s: unaligned", who);
     const int NS = F / ML_SL;
-    const long total = 4L * ((wo ? ML_P0 : 0) + (long)NS * (2 * ML_FPP) + ML_PF) * 64;
+    const long total = 4L * ((wo ? ML_P0 : 0) + (long)NS * ((f8 ? ML_FPP / 2 : ML_FPP) + ML_FPP) + ML_PF) * 64;
     hipLaunchKernelGGL(mlp_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)wo, (const bf16_t*)w1, (const bf16_t*)w2, (uint4*)stream_out, NS);
+                       (const bf16_t*)wo, w1, (const bf16_t*)w2, (uint4*)stream_out, NS, f8);
     SWC_CHECK_LAUNCH(who);
     return SWC_OK;
 }
@@ -639,45 +790,54 @@ extern "C" int swc_mlp_block(const float* x, float* x_out, const float* ln_w, co
                       aligned16(b2) && aligned16(next_ln_w) && aligned16(next_ln_b) && aligned16(y_next),
                   "swc_mlp_block: unaligned");
     if (M == 0) return SWC_OK;
-    SWC_ENABLE_LDS(mlp_block_kernel<false>, ML_LDS, "swc_mlp_block");
+    SWC_ENABLE_LDS((mlp_block_kernel<false, false>), ML_LDS, "swc_mlp_block");
     const unsigned grid = (unsigned)((M + ML_BM - 1) / ML_BM);
-    hipLaunchKernelGGL(mlp_block_kernel<false>, dim3(grid), dim3(256), ML_LDS, (hipStream_t)stream, x, x_out, MlNorm{ln_w, ln_b},
+    hipLaunchKernelGGL((mlp_block_kernel<false, false>), dim3(grid), dim3(256), ML_LDS, (hipStream_t)stream, x, x_out, MlNorm{ln_w, ln_b},
                        eps, (const u32x4*)w_stream, b1, b2, MlNorm{next_ln_w, next_ln_b}, (bf16_t*)y_next, M, F / ML_SL,
-                       (const bf16_t*)nullptr, (const float*)nullptr);
+                       (const bf16_t*)nullptr, (const float*)nullptr, 1.0f, (unsigned*)nullptr);
     SWC_CHECK_LAUNCH("swc_mlp_block");
     return SWC_OK;
 }
 
-extern "C" int64_t swc_layer_tail_stream_bytes(int32_t D, int32_t F) {
-    if (D != ML_D || F <= 0 || F % ML_SL != 0) return 0;
-    return 4L * (ML_P0 + (long)(F / ML_SL) * (2 * ML_FPP) + ML_PF) * 1024;
+extern "C" int64_t swc_layer_tail_stream_bytes(int32_t D, int32_t F, int32_t fc1_dtype) {
+    if (D != ML_D || F <= 0 || F % ML_SL != 0 || (fc1_dtype != SWC_BF16 && fc1_dtype != SWC_FP8)) return 0;
+    return 4L * (ML_P0 + (long)(F / ML_SL) * ((fc1_dtype == SWC_FP8 ? ML_FPP / 2 : ML_FPP) + ML_FPP) + ML_PF) * 1024;
 }
 
 extern "C" int swc_layer_tail_pack(const void* wo, const void* w1, const void* w2, void* stream_out, int32_t D, int32_t F,
-                                   void* stream) {
+                                   int32_t fc1_dtype, void* stream) {
     SWC_CHECK_ARG(wo, "swc_layer_tail_pack: null pointer");
-    return ml_pack(wo, w1, w2, stream_out, D, F, stream, "swc_layer_tail_pack");
+    SWC_CHECK_ARG(fc1_dtype == SWC_BF16 || fc1_dtype == SWC_FP8, "swc_layer_tail_pack: fc1_dtype must be BF16 or FP8");
+    return ml_pack(wo, w1, w2, stream_out, D, F, stream, "swc_layer_tail_pack", fc1_dtype == SWC_FP8);
 }
 
 extern "C" int swc_layer_tail(const void* attn, const float* x, float* x_out, const void* w_stream, const float* bo,
                               const float* ln_w, const float* ln_b, float eps, const float* b1, const float* b2,
                               const float* next_ln_w, const float* next_ln_b, void* y_next, int32_t M, int32_t D, int32_t F,
-                              void* stream) {
+                              int32_t fc1_dtype, float fc1_alpha, void* stream) {
     SWC_CHECK_ARG(attn && x && x_out && bo && ln_w && ln_b && w_stream && b1 && b2, "swc_layer_tail: null pointer");
     SWC_CHECK_ARG(!y_next || (next_ln_w && next_ln_b), "swc_layer_tail: y_next needs next_ln_w / next_ln_b");
     SWC_CHECK_ARG(D == ML_D && F > 0 && F % ML_SL == 0, "swc_layer_tail: needs D = %d and F a multiple of %d (D=%d F=%d)", ML_D,
                   ML_SL, D, F);
+    SWC_CHECK_ARG(fc1_dtype == SWC_BF16 || fc1_dtype == SWC_FP8, "swc_layer_tail: fc1_dtype must be BF16 or FP8");
     SWC_CHECK_ARG(M >= 0, "swc_layer_tail: bad M");
     SWC_CHECK_ARG(aligned16(attn) && aligned16(x) && aligned16(x_out) && aligned16(bo) && aligned16(ln_w) && aligned16(ln_b) &&
                       aligned16(w_stream) && aligned16(b1) && aligned16(b2) && aligned16(next_ln_w) && aligned16(next_ln_b) &&
                       aligned16(y_next),
                   "swc_layer_tail: unaligned");
     if (M == 0) return SWC_OK;
-    SWC_ENABLE_LDS(mlp_block_kernel<true>, ML_LDS, "swc_layer_tail");
     const unsigned grid = (unsigned)((M + ML_BM - 1) / ML_BM);
-    hipLaunchKernelGGL(mlp_block_kernel<true>, dim3(grid), dim3(256), ML_LDS, (hipStream_t)stream, x, x_out, MlNorm{ln_w, ln_b},
-                       eps, (const u32x4*)w_stream, b1, b2, MlNorm{next_ln_w, next_ln_b}, (bf16_t*)y_next, M, F / ML_SL,
-                       (const bf16_t*)attn, bo);
+    if (fc1_dtype == SWC_FP8) {
+        SWC_ENABLE_LDS((mlp_block_kernel<true, true>), ML_LDS, "swc_layer_tail");
+        hipLaunchKernelGGL((mlp_block_kernel<true, true>), dim3(grid), dim3(256), ML_LDS, (hipStream_t)stream, x, x_out,
+                           MlNorm{ln_w, ln_b}, eps, (const u32x4*)w_stream, b1, b2, MlNorm{next_ln_w, next_ln_b}, (bf16_t*)y_next, M,
+                           F / ML_SL, (const bf16_t*)attn, bo, fc1_alpha, swc_sat_counter());
+    } else {
+        SWC_ENABLE_LDS((mlp_block_kernel<true, false>), ML_LDS, "swc_layer_tail");
+        hipLaunchKernelGGL((mlp_block_kernel<true, false>), dim3(grid), dim3(256), ML_LDS, (hipStream_t)stream, x, x_out,
+                           MlNorm{ln_w, ln_b}, eps, (const u32x4*)w_stream, b1, b2, MlNorm{next_ln_w, next_ln_b}, (bf16_t*)y_next, M,
+                           F / ML_SL, (const bf16_t*)attn, bo, 1.0f, (unsigned*)nullptr);
+    }
     SWC_CHECK_LAUNCH("swc_layer_tail");
     return SWC_OK;
 }

@@ -411,29 +411,36 @@ def mlp_block(x, ln_w, ln_b, eps, w_stream, b1, b2, *, M, D, F, x_out=None, next
 
 
 def layer_tail_pack(wo, w1, w2):
-    """out_proj.weight [D, D], fc1.weight [F, D], fc2.weight [D, F] (bf16, device) -> the operand stream of swc_layer_tail."""
+    """out_proj.weight [D, D] (bf16), fc1.weight [F, D] (bf16, or e4m3 at a per-tensor scale: preset fp8_fc1), fc2.weight [D, F]
+    (bf16), all on the device -> the operand stream of swc_layer_tail for that fc1 operand type."""
     lib = _lib.load()
-    _chk(wo, "layer_tail_pack wo", torch.bfloat16); _chk(w1, "layer_tail_pack w1", torch.bfloat16)
-    _chk(w2, "layer_tail_pack w2", torch.bfloat16)
+    _chk(wo, "layer_tail_pack wo", torch.bfloat16); _chk(w2, "layer_tail_pack w2", torch.bfloat16)
+    _chk(w1, "layer_tail_pack w1")
+    if w1.dtype not in (torch.bfloat16, FP8_T):
+        raise _lib.SwcError(f"layer_tail_pack: fc1 weights must be bf16 or e4m3, got {w1.dtype}")
     F_, D = w1.shape
     if tuple(w2.shape) != (D, F_) or tuple(wo.shape) != (D, D):
         raise _lib.SwcError(f"layer_tail_pack: shapes {tuple(wo.shape)} {tuple(w1.shape)} {tuple(w2.shape)}")
-    n = lib.swc_layer_tail_stream_bytes(D, F_)
+    n = lib.swc_layer_tail_stream_bytes(D, F_, _DT[w1.dtype])
     if n <= 0:
         raise _lib.SwcError(f"layer_tail_pack: unsupported geometry D={D} F={F_}")
     out = torch.empty(n, dtype=torch.uint8, device=w1.device)
     _lib.check(lib.swc_layer_tail_pack(_ptr(wo.contiguous()), _ptr(w1.contiguous()), _ptr(w2.contiguous()), _ptr(out), D, F_,
-                                       _stream()), "swc_layer_tail_pack")
+                                       _DT[w1.dtype], _stream()), "swc_layer_tail_pack")
     return out
 
 
-def layer_tail(attn, x, w_stream, bo, ln_w, ln_b, eps, b1, b2, *, M, D, F, x_out=None, next_ln=None, y_next=None):
+def layer_tail(attn, x, w_stream, bo, ln_w, ln_b, eps, b1, b2, *, M, D, F, x_out=None, next_ln=None, y_next=None,
+               fc1_dtype=torch.bfloat16, fc1_alpha=1.0):
     """Everything of a transformer layer behind the attention in one kernel (swc_layer_tail): attn [M, D] bf16 (attention
     output), x [M, D] f32 residual stream -> x_out (default: in place) and, with next_ln = (weight, bias), the bf16
-    LayerNorm output the next layer's q/k/v projection reads (second return value)."""
+    LayerNorm output the next layer's q/k/v projection reads (second return value).  fc1_dtype = FP8_T: the stream was packed
+    from e4m3 fc1 weights (scale sw) and fc1_alpha = 1 / (FP8_ACT_SCALE * sw)."""
     lib = _lib.load()
     _chk(attn, "layer_tail attn", torch.bfloat16); _chk(x, "layer_tail x", torch.float32)
     x_out = x if x_out is None else _chk(x_out, "layer_tail x_out", torch.float32)
+    if w_stream.numel() != lib.swc_layer_tail_stream_bytes(D, F, _DT[fc1_dtype]):
+        raise _lib.SwcError(f"layer_tail: the operand stream ({w_stream.numel()} bytes) was not packed for fc1 operands {fc1_dtype}")
     nw = nb = None
     if next_ln is not None:
         nw, nb = next_ln
@@ -444,9 +451,10 @@ def layer_tail(attn, x, w_stream, bo, ln_w, ln_b, eps, b1, b2, *, M, D, F, x_out
         y_next = None
     prof = PROFILER
     if prof is not None:
-        prof.begin("mlp_bf16", 4.0 * M * D * F + 2.0 * M * D * D)
+        prof.begin("mlp_bf16" if fc1_dtype == torch.bfloat16 else "mlp_fp8fc1", 4.0 * M * D * F + 2.0 * M * D * D)
     _lib.check(lib.swc_layer_tail(_ptr(attn), _ptr(x), _ptr(x_out), _ptr(w_stream), _ptr(bo), _ptr(ln_w), _ptr(ln_b), eps, _ptr(b1),
-                                  _ptr(b2), _ptr(nw), _ptr(nb), _ptr(y_next), M, D, F, _stream()), "swc_layer_tail")
+                                  _ptr(b2), _ptr(nw), _ptr(nb), _ptr(y_next), M, D, F, _DT[fc1_dtype], float(fc1_alpha), _stream()),
+               "swc_layer_tail")
     if prof is not None:
         prof.end()
     return x_out, y_next

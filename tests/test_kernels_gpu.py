@@ -951,3 +951,51 @@ def test_layer_tail_fused(M, F_, with_next):
                    next_ln=(d(nw), d(nb)) if with_next else None)
     assert torch.equal(xin.cpu(), x0) and torch.equal(out, xo)
 
+
+
+@pytest.mark.parametrize("M,F_", [(64, 256), (300, 512), (77, 256), (16000, 3072)])
+def test_layer_tail_fp8_fc1(M, F_):
+    """swc_layer_tail with fc1 on the block-scaled fp8 MFMA (preset fp8_fc1): against (a) an f64 evaluation on the SAME quantised
+    operands (LayerNorm output rounded to e4m3 at scale 16, e4m3 fc1 weights at their power-of-two scale, GELU output rounded
+    to bf16) and (b) the unfused launches of the preset (swc_layernorm -> e4m3, fp8 swc_gemm + GELU -> bf16, bf16 swc_gemm)."""
+    ops = _ops()
+    D = 768
+    g = torch.Generator().manual_seed(M * 13 + F_)
+    x0 = torch.randn(M, D, generator=g) * 1.5 + 0.1
+    att = (torch.randn(M, D, generator=g) * 0.7).to(torch.bfloat16)
+    wo = (torch.randn(D, D, generator=g) * D ** -0.5).to(torch.bfloat16)
+    bo = torch.randn(D, generator=g) * 0.2
+    lw, lb = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    nw, nb = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    w1f = torch.randn(F_, D, generator=g) * D ** -0.5
+    w2 = (torch.randn(D, F_, generator=g) * F_ ** -0.5).to(torch.bfloat16)
+    b1, b2 = torch.randn(F_, generator=g) * 0.3, torch.randn(D, generator=g) * 0.3
+    d = lambda t: t.to(DEV)
+    import math
+    sw = 2.0 ** math.floor(math.log2(448.0 / float(w1f.abs().max())))
+    w1q = ops.cast_fp8(d(w1f), sw)                      # e4m3 bytes of w1 * sw
+    alpha = 1.0 / (ops.FP8_ACT_SCALE * sw)
+    wts = ops.layer_tail_pack(d(wo), w1q, d(w2))
+    x = d(x0).clone()
+    xo, yn = ops.layer_tail(d(att), x, wts, d(bo), d(lw), d(lb), 1e-5, d(b1), d(b2), M=M, D=D, F=F_, next_ln=(d(nw), d(nb)),
+                            fc1_dtype=ops.FP8_T, fc1_alpha=alpha)
+    assert torch.isfinite(xo).all() and yn.dtype == torch.bfloat16
+    # (b) the unfused launches of the preset
+    x2 = d(x0).clone()
+    ops.gemm(d(att), d(wo), M, D, D, bias=d(bo), residual=x2, out=x2)
+    y8 = ops.layernorm(x2, d(lw), d(lb), 1e-5, B=1, t_in=M, C_=D, out_dtype=ops.FP8_T).view(M, D)
+    hh = ops.gemm(y8, w1q, M, F_, D, bias=d(b1), act=ops.ACT_GELU, out_dtype=torch.bfloat16, alpha=alpha)
+    xp = x2.clone()                                     # x' of the unfused path
+    ops.gemm(hh, d(w2), M, D, F_, bias=d(b2), residual=x2, out=x2)
+    # (a) f64 on the unfused path's own quantised operands
+    yq = y8.float().cpu().double() / ops.FP8_ACT_SCALE
+    wq = w1q.float().cpu().double() / sw
+    h = F.gelu(yq @ wq.T + b1.double()).to(torch.bfloat16).double()
+    ref = xp.cpu().double() + h @ w2.double().T + b2.double()
+    scale = float((ref - x0.double()).abs().max())
+    e_ref = float((xo.cpu().double() - ref).abs().max()) / scale
+    e_two = float((xo.cpu().double() - x2.cpu().double()).abs().max()) / scale
+    # the fused kernel normalises x' in another summation order: an e4m3 rounding of y can tip (2^-4 relative on one element)
+    assert e_ref < 2e-2 and e_two < 2e-2, (e_ref, e_two)
+    want = ops.layernorm(xo, d(nw), d(nb), 1e-5, B=1, t_in=M, C_=D, out_dtype=torch.bfloat16).view(M, D)
+    assert torch.equal(yn, want)

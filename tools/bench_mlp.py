@@ -52,6 +52,18 @@ def tail(i):  # out-proj + the whole MLP sub-block + next LayerNorm: one kernel
     ops.layer_tail(att[i % NB], xs[i % NB], wts, bo, lw, lb, 1e-5, b1, b2, M=M, D=D, F=F_, next_ln=(lw, lb), y_next=yn)
 
 
+import math
+w1f = torch.randn(F_, D, device=dev, generator=g) * D ** -0.5
+sw8 = 2.0 ** math.floor(math.log2(448.0 / float(w1f.abs().max())))
+w1q = ops.cast_fp8(w1f, sw8)
+wt8 = ops.layer_tail_pack(wo, w1q, w2)
+
+
+def tail_fp8(i):  # the same kernel with fc1 on the block-scaled fp8 MFMA (preset fp8_fc1)
+    ops.layer_tail(att[i % NB], xs[i % NB], wt8, bo, lw, lb, 1e-5, b1, b2, M=M, D=D, F=F_, next_ln=(lw, lb), y_next=yn,
+                   fc1_dtype=ops.FP8_T, fc1_alpha=1.0 / (ops.FP8_ACT_SCALE * sw8))
+
+
 def oproj_fused(i):  # the same work as two launches: out-proj GEMM, swc_mlp_block
     x = xs[i % NB]
     ops.gemm(att[i % NB], wo, M, D, D, bias=bo, residual=x, out=x)
@@ -64,7 +76,7 @@ def oproj_four(i):  # ... and as the five launches of round 3
     four(i)
 
 
-ALL = (("layer_tail", tail), ("oproj+fused", oproj_fused), ("oproj+ln+2gemm+ln", oproj_four), ("fused", fused), ("fused_no_next", fused_no_next), ("ln+2gemm+ln", four), ("two_gemm", two_gemm))
+ALL = (("layer_tail fp8fc1", tail_fp8), ("layer_tail", tail), ("oproj+fused", oproj_fused), ("oproj+ln+2gemm+ln", oproj_four), ("fused", fused), ("fused_no_next", fused_no_next), ("ln+2gemm+ln", four), ("two_gemm", two_gemm))
 res = {n: [] for n, _ in ALL}
 for _, fn in ALL:
     for i in range(3):
