@@ -307,6 +307,12 @@ class AudioCodec(nn.Module):
             ev.record()
         st["snap_ev"] = ev
 
+    def _lazy_fp8_check(self, ran_as):
+        """account for the snapshot the PREVIOUS fp8-preset call left behind, if its event has completed (no waiting)"""
+        st = self.__dict__.get("_sat")
+        if st is not None and st["snap_ev"] is not None and st["snap_ev"].query():
+            self._check_clipping(ran_as, snapshot=True)
+
     class _Deferred:
         """`with model.deferred_range_check() as chk:` — inside, encode-side calls do not read the clip counters back (no
         stream synchronisation between encode and the work enqueued after it); leaving the block reads them once — from a
@@ -402,6 +408,14 @@ class AudioCodec(nn.Module):
         e = PRECISIONS[ran_as][0]
         if (e != "f16s" and ran_as not in ("fp8", "fp8_fc1")) or self.saturation_policy == "off":
             return run(P)
+        if e != "f16s":
+            # fp8 presets: clipping is part of the preset's stated tolerance — counted and warned about, never re-run — so
+            # nothing has to wait for the counters: they are snapshotted behind this call's kernels and looked at when the next
+            # call comes in (round 4: the blocking read-back cost 0.4 ms of a 14.9 ms step, tools/probes/cmp_presets.py)
+            self._lazy_fp8_check(ran_as)
+            out = run(P)
+            self._snapshot_counters()
+            return out
         out = run(P)
         if self.__dict__.get("_defer", 0) > 0:  # inside deferred_range_check(): one read-back when the block ends
             self.__dict__["_defer_pending"] = True
