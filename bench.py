@@ -637,7 +637,7 @@ def main():
         if cpu_res is not None:
             if args.cpu_baseline == "sample":
                 cpu_res["full_shapes"] = ("B = 8 and B = 32 x 10 s (BASELINE.md 2) with `--cpu-baseline full`: "
-                                          "profiles/r02_cpu_baseline_full.json (5.37 / 5.65 audio-s/s, 16 threads, EPYC 9575F)")
+                                          "profiles/r04_cpu_baseline_full.json (5.97 / 5.80 audio-s/s, 16 threads = the cgroup quota, EPYC 9575F)")
             line["cpu_baseline"] = cpu_res
         print(json.dumps(line), flush=True)
     if use_dist:
