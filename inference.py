@@ -147,8 +147,19 @@ def main(argv=None):
         paths, wav_list = item
         with torch.no_grad():
             t1 = time.perf_counter()
-            codes_list = model.encode(wav_list, overlap_seconds=10, device=device)["codes_list"]
-            syn = model.decode(codes_list, overlap_seconds=10, device=device)["syn_wav_list"]
+            def round_trip():
+                codes = model.encode(wav_list, overlap_seconds=10, device=device)["codes_list"]
+                return codes, model.decode(codes, overlap_seconds=10, device=device)["syn_wav_list"]
+            # the range check of the split-f16 encoder is read from a snapshot behind the encode kernels once the decode has been
+            # enqueued (no stall between the two calls); a clipped batch is redone on exact-f32 operands
+            defer = getattr(model, "deferred_range_check", None)
+            if defer is None or not on_gpu:
+                codes_list, syn = round_trip()
+            else:
+                with defer() as chk:
+                    codes_list, syn = round_trip()
+                if chk.clipped:
+                    codes_list, syn = round_trip()
             out = stager.pcm16_on_device(syn) if on_gpu else [w.cpu() for w in syn]
             if on_gpu:
                 torch.cuda.current_stream().synchronize()
