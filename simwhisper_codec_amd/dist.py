@@ -90,26 +90,31 @@ class DataParallelCodec:
                 raise error
             return [int(v) for v in values]
         cap = self._INTS_CAP
-        if self.rank == 0:
-            vals = [int(v) for v in values] if error is None else []
-            head = ([len(vals)] + vals[: cap - 1]) if error is None else [-1]
-            t = torch.tensor(head + [0] * (cap - len(head)), dtype=torch.int64, device=self.comm)
-        else:
-            t = torch.empty(cap, dtype=torch.int64, device=self.comm)
-        dist.broadcast(t, src=0, group=self.group)
-        got = t.tolist()
-        k = int(got[0])
-        if k < 0:
-            if error is not None:
-                raise error
-            raise RuntimeError("DataParallelCodec: rank 0 could not assemble this batch (see its log); the step is abandoned "
-                               "on every rank")
-        out = got[1: 1 + min(k, cap - 1)]
-        if k > cap - 1:
-            rest = torch.tensor(vals[cap - 1:], dtype=torch.int64, device=self.comm) if self.rank == 0 else \
-                torch.empty(k - (cap - 1), dtype=torch.int64, device=self.comm)
-            dist.broadcast(rest, src=0, group=self.group)
-            out += rest.tolist()
+        # (RCCL: from the side stream — the lengths are host data on rank 0 and nothing on the compute stream produces them, so
+        # reading them back must not wait for the previous step's kernels still queued there; the host then runs a step ahead
+        # and back-pressure comes from the data dependencies of the sends alone)
+        side = self._status_stream()
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            if self.rank == 0:
+                vals = [int(v) for v in values] if error is None else []
+                head = ([len(vals)] + vals[: cap - 1]) if error is None else [-1]
+                t = torch.tensor(head + [0] * (cap - len(head)), dtype=torch.int64, device=self.comm)
+            else:
+                t = torch.empty(cap, dtype=torch.int64, device=self.comm)
+            dist.broadcast(t, src=0, group=self.group)
+            got = t.tolist()
+            k = int(got[0])
+            if k < 0:
+                if error is not None:
+                    raise error
+                raise RuntimeError("DataParallelCodec: rank 0 could not assemble this batch (see its log); the step is abandoned "
+                                   "on every rank")
+            out = got[1: 1 + min(k, cap - 1)]
+            if k > cap - 1:
+                rest = torch.tensor(vals[cap - 1:], dtype=torch.int64, device=self.comm) if self.rank == 0 else \
+                    torch.empty(k - (cap - 1), dtype=torch.int64, device=self.comm)
+                dist.broadcast(rest, src=0, group=self.group)
+                out += rest.tolist()
         return [int(v) for v in out]
 
     def _agree(self, error):
