@@ -200,6 +200,17 @@ int swc_convnext_block(const float* x, float* x_out, const float* dw_w7, const f
                        void* stream);
 
 /*
+ * EXPERIMENT (round 4, not on the product path): swc_convnext_mlp on 64-frame tiles with two workgroups
+ * per CU (2 waves per SIMD, 80 KiB of LDS each) and an optional start stagger of the second workgroup of every CU
+ * (`stagger_cycles` shader cycles, 0 = none), so that one workgroup's HBM phases fall into the other's slice loop.  Same
+ * arithmetic, operand types and arguments as swc_convnext_mlp; its own packed stream (swc_convnext64_pack).
+ */
+int64_t swc_convnext64_stream_bytes(int32_t C, int32_t I);
+int swc_convnext64_pack(const void* w1_bf16, const void* w2_bf16, void* w_stream, int32_t C, int32_t I, void* stream);
+int swc_convnext64_mlp(const void* y, const void* w_stream, const float* b1, const float* b2, const float* gamma, float* x,
+                       int32_t M, int32_t C, int32_t I, int32_t stagger_cycles, void* stream);
+
+/*
  * The MLP sub-block of one OmniWhisperTransformerLayer in one kernel (modules.py:224-232: final_layer_norm -> fc1 ->
  * exact GELU -> fc2 -> + residual), 12x per encoder / decoder call:
  *     x_out[M][D] = x + ( GELU( LayerNorm(x; ln_w, ln_b, eps) W1^T + b1 ) W2^T + b2 )

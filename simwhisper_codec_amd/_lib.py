@@ -73,6 +73,8 @@ SIGNATURES = {
     "swc_convnext_pack": [_P, _P, _P, _P, _I, _I, _P],
     "swc_convnext_mlp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "swc_convnext_block": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "swc_convnext64_pack": [_P, _P, _P, _I, _I, _P],
+    "swc_convnext64_mlp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "swc_mlp_pack": [_P, _P, _P, _I, _I, _P],
     "swc_mlp_block": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "swc_layer_tail_pack": [_P, _P, _P, _P, _I, _I, _I, _P],
@@ -80,7 +82,7 @@ SIGNATURES = {
 }
 PLAIN = {"swc_version": ([], C.c_int), "swc_last_error": ([], C.c_char_p), "swc_device_count": ([], C.c_int),
          "swc_convnext_stream_bytes": ([_I, _I], C.c_int64),
-         "swc_mlp_stream_bytes": ([_I, _I], C.c_int64), "swc_layer_tail_stream_bytes": ([_I, _I, _I], C.c_int64)}
+         "swc_mlp_stream_bytes": ([_I, _I], C.c_int64), "swc_convnext64_stream_bytes": ([_I, _I], C.c_int64), "swc_layer_tail_stream_bytes": ([_I, _I, _I], C.c_int64)}
 
 _lib = None
 

@@ -344,6 +344,28 @@ def convnext_mlp(y, w_stream, b1, b2, gamma, x, *, M, C_, I):
     return x
 
 
+def convnext64_pack(w1, w2):
+    """EXPERIMENT (swc_convnext64_mlp): pwconv1.weight [I, C] and pwconv2.weight [C, I] (bf16, device) -> its operand stream."""
+    lib = _lib.load()
+    _chk(w1, "convnext64_pack w1", torch.bfloat16); _chk(w2, "convnext64_pack w2", torch.bfloat16)
+    I, C_ = w1.shape
+    n = lib.swc_convnext64_stream_bytes(C_, I)
+    if n <= 0 or tuple(w2.shape) != (C_, I):
+        raise _lib.SwcError(f"convnext64_pack: unsupported geometry C={C_} I={I}")
+    out = torch.empty(n, dtype=torch.uint8, device=w1.device)
+    _lib.check(lib.swc_convnext64_pack(_ptr(w1.contiguous()), _ptr(w2.contiguous()), _ptr(out), C_, I, _stream()), "swc_convnext64_pack")
+    return out
+
+
+def convnext64_mlp(y, w_stream, b1, b2, gamma, x, *, M, C_, I, stagger_cycles=0):
+    """EXPERIMENT: swc_convnext_mlp on 64-frame tiles, two workgroups per CU, optional start stagger (shader cycles)."""
+    lib = _lib.load()
+    _chk(y, "convnext64_mlp y", torch.bfloat16); _chk(x, "convnext64_mlp x", torch.float32)
+    _lib.check(lib.swc_convnext64_mlp(_ptr(y), _ptr(w_stream), _ptr(b1), _ptr(b2), _ptr(gamma), _ptr(x), M, C_, I, int(stagger_cycles),
+                                      _stream()), "swc_convnext64_mlp")
+    return x
+
+
 def abi_version():
     return int(_lib.load().swc_version())
 

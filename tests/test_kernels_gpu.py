@@ -999,3 +999,25 @@ def test_layer_tail_fp8_fc1(M, F_):
     assert e_ref < 2e-2 and e_two < 2e-2, (e_ref, e_two)
     want = ops.layernorm(xo, d(nw), d(nb), 1e-5, B=1, t_in=M, C_=D, out_dtype=torch.bfloat16).view(M, D)
     assert torch.equal(yn, want)
+
+
+@pytest.mark.parametrize("M,I,stagger", [(300, 256, 0), (64, 128, 0), (1000, 4096, 0), (32000, 4096, 20000)])
+def test_convnext64_experiment_matches_the_shipped_kernel(M, I, stagger):
+    """swc_convnext64_mlp (round-4 experiment: 64-frame tiles, two workgroups per CU, optional start stagger) against
+    swc_convnext_mlp on the same operands: the same products in another tile shape (accumulation order differs per 32-bit
+    rounding only)."""
+    ops = _ops()
+    C = 512
+    g = torch.Generator().manual_seed(M + I)
+    y = torch.randn(M, C, generator=g).to(torch.bfloat16).to(DEV)
+    w1 = (torch.randn(I, C, generator=g) * C ** -0.5).to(torch.bfloat16).to(DEV)
+    w2 = (torch.randn(C, I, generator=g) * I ** -0.5).to(torch.bfloat16).to(DEV)
+    b1, b2, gam = (torch.randn(I, generator=g) * 0.3).to(DEV), (torch.randn(C, generator=g) * 0.3).to(DEV), torch.randn(C, generator=g).to(DEV)
+    x0 = torch.randn(M, C, generator=g).to(DEV)
+    xa = x0.clone()
+    ops.convnext_mlp(y, ops.convnext_pack(w1, w2, gam), b1, b2, gam, xa, M=M, C_=C, I=I)
+    xb = x0.clone()
+    ops.convnext64_mlp(y, ops.convnext64_pack(w1, w2), b1, b2, gam, xb, M=M, C_=C, I=I, stagger_cycles=stagger)
+    scale = float((xa - x0).abs().max())
+    assert torch.isfinite(xb).all()
+    assert float((xa - xb).abs().max()) / scale < 2e-3

@@ -49,8 +49,19 @@ def two(i):
     ops.gemm(hh, w2, M, C, I, bias=b2, gamma=gam, residual=xs[i % NB], out=xs[i % NB])
 
 
-res = {"fused": [], "two_gemm": [], "block": [], "dw+mlp": [], "dw+2gemm": []}
-ALL = (("fused", fused), ("two_gemm", two), ("block", block), ("dw+mlp", dw_mlp), ("dw+2gemm", three))
+ws64 = ops.convnext64_pack(w1, w2)
+STAG = [int(v) for v in os.environ.get("CX64_STAGGER", "0,20000,40000,80000").split(",")]
+
+
+def mk64(st):
+    def f(i):  # the round-4 experiment: 64-frame tiles, two workgroups per CU, second one started `st` cycles late
+        ops.convnext64_mlp(ys[i % NB], ws64, b1, b2, gam, xs[i % NB], M=M, C_=C, I=I, stagger_cycles=st)
+    return f
+
+
+ALL = (("fused", fused), ("two_gemm", two), ("block", block), ("dw+mlp", dw_mlp), ("dw+2gemm", three)) + tuple(
+    (f"mlp64 st{st}", mk64(st)) for st in STAG)
+res = {n: [] for n, _ in ALL}
 for _, fn in ALL:
     for i in range(3):
         fn(i)
@@ -66,4 +77,4 @@ for rnd in range(7):
 fl = 4.0 * M * C * I
 for name, ts in res.items():
     t = statistics.median(ts)
-    print(f"{name:9s} M={M} {t*1e3:8.1f} us  {fl/t/1e9:8.1f} TFLOP/s   (min {min(ts)*1e3:.1f} us)")
+    print(f"{name:14s} M={M} {t*1e3:8.1f} us  {fl/t/1e9:8.1f} TFLOP/s   (min {min(ts)*1e3:.1f} us)")
