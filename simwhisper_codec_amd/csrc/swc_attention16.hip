@@ -73,8 +73,12 @@ __device__ __forceinline__ unsigned pack2_f16(float lo, float hi) {
 
 // KT16: keys per tile (64, or 128 for the bf16 kernel: half the fences and dependent softmax chains per key)
 // NQT: 16-query MFMA tiles per wave (2: 128 queries per workgroup; 1: 64 — half the registers, twice the waves per SIMD)
-template <int PLANES, int KT16, int NQT>
-__global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const char* __restrict__ qkv, unsigned short* __restrict__ out,
+// RES (build option -DATT_RES=1, bf16 only, T <= 512; round 4, measured, not the default): one workgroup of 8 waves per
+// (utterance, head) keeps ALL of its K and V in LDS (8 tiles x 16 KiB = 128 KiB), staged once, and its waves walk the query
+// blocks (32 queries per wave, 256 per pass) with no further staging, fence or barrier.  Removes the re-staging of K / V by every
+// 128-query workgroup (4 x per (utterance, head) at T = 500) at the price of one workgroup per CU and 384 workgroups on 256 CUs.
+template <int PLANES, int KT16, int NQT, bool RES = false>
+__global__ __launch_bounds__(RES ? 512 : 256, RES ? 1 : (NQT == 1 ? 4 : 2)) void attn16_kernel(const char* __restrict__ qkv, unsigned short* __restrict__ out,
                                                         const int* __restrict__ lens, int T, int H,
                                                         const int* __restrict__ row_start) {
     constexpr int ROWB = 128 * PLANES;    // bytes of one (token, head) row: 64 bf16, or [32 hi|32 lo|32 hi|32 lo] f16
@@ -87,7 +91,9 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
     constexpr int NI = TILE / 1024;       // LDS-DMA wave-instructions per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
 
-    const int b = blockIdx.z, head = blockIdx.y, q0 = blockIdx.x * QB16;
+    constexpr int NW = RES ? 8 : 4;       // waves per workgroup
+    const int b = blockIdx.z, head = blockIdx.y;
+    int q0 = RES ? 0 : blockIdx.x * QB16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fh = lane >> 4;
     const int D = H * 64;
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
         }
     };
 
-    if (q0 >= len) {  // whole block is padding: defined, finite output
+    if (!RES && q0 >= len) {  // whole block is padding: defined, finite output
 #pragma unroll
         for (int qt = 0; qt < NQT; ++qt)
 #pragma unroll
@@ -128,19 +134,21 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
 
     // ---- Q fragments (B operand of S^T): [qt][g][plane]
     uint4 qf[NQT][2][PLANES];
+    auto load_q = [&]() {
 #pragma unroll
-    for (int qt = 0; qt < NQT; ++qt) {
-        int q = q0 + wave * QW + qt * 16 + fr;
-        q = q < qlim ? q : qlim - 1;
-        const char* qp = base + (long)q * ldb;
+        for (int qt = 0; qt < NQT; ++qt) {
+            int q = q0 + wave * QW + qt * 16 + fr;
+            q = q < qlim ? q : qlim - 1;
+            const char* qp = base + (long)q * ldb;
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+            for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int pl = 0; pl < PLANES; ++pl) {
-                const int c = PLANES == 1 ? (4 * g + fh) : (8 * g + 4 * pl + fh);
-                qf[qt][g][pl] = *reinterpret_cast<const uint4*>(qp + 16 * c);
-            }
-    }
+                for (int pl = 0; pl < PLANES; ++pl) {
+                    const int c = PLANES == 1 ? (4 * g + fh) : (8 * g + 4 * pl + fh);
+                    qf[qt][g][pl] = *reinterpret_cast<const uint4*>(qp + 16 * c);
+                }
+        }
+    };
 
     // ---- staging geometry (LDS-DMA, lane-linear 1 KiB per wave-instruction, swizzle on the source)
     const unsigned smem_base = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)smem);
@@ -150,8 +158,9 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
         const int k0 = kt * KT16;
         const char* zero = reinterpret_cast<const char*>(g_zero16a);
 #pragma unroll
-        for (int j = 0; j < NI / 4; ++j) {
-            const int inst = wave_u + 4 * j;
+        for (int j = 0; j < (NI + NW - 1) / NW; ++j) {
+            const int inst = wave_u + NW * j;
+            if (NI % NW != 0 && inst >= NI) break;
             const int row = inst * (64 / CPR) + l_row;
             const int key = k0 + row;
             const bool ok = key < len;
@@ -175,20 +184,21 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
     };
 
     f32x4 o[NQT][4];
-#pragma unroll
-    for (int qt = 0; qt < NQT; ++qt)
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m_run[NQT];
-#pragma unroll
-    for (int qt = 0; qt < NQT; ++qt) m_run[qt] = -INFINITY;
     // Row sums of P on the matrix pipe (the softmax is VALU-bound at head_dim 64: 250 VALU against 32 MFMA issue slots per
     // key tile in the bf16 kernel): l^T = ONES[16 x keys] P^T[keys x q] accumulates beside O^T and is rescaled with it;
     // every row of the tile holds the sum of the operands actually multiplied into O (rounded P, hi + lo for split-f16),
     // already complete over the wave — no per-element adds, no cross-lane reduction at the end.
     f32x4 lacc[NQT];
+    auto init_acc = [&]() {
 #pragma unroll
-    for (int qt = 0; qt < NQT; ++qt) lacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int qt = 0; qt < NQT; ++qt) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            m_run[qt] = -INFINITY;
+            lacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
     const unsigned one2 = PLANES == 1 ? 0x3F803F80u : 0x3C003C00u;  // (1.0, 1.0) as bf16 / f16
     const uint4 ones = make_uint4(one2, one2, one2, one2);
     // Softmax exponentials: raw scores (split-f16: still carrying the operand scales 64 * 64), running maximum in
@@ -203,14 +213,12 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
     const float m_off = PLANES == 1 ? 0.0f : 11.0f / c_exp;
 
     const int ntile = (len + KT16 - 1) / KT16;
-    stage(0, 0);
-    fence();
     // one key tile; LAST: the tile may hold keys >= len (masking and the -inf guards are compiled only there)
     auto tile = [&](int kt, auto last_c) {
         constexpr bool LAST = decltype(last_c)::value;
-        const int st = kt & 1;
+        const int st = RES ? kt : (kt & 1);   // RES: every tile has its own slot, staged once before the query loop
 #if !(defined(ATT_ABL) && (ATT_ABL & 32))   // timing ablation only (wrong results): the next tile is not staged
-        if (!LAST) stage(kt + 1, st ^ 1);
+        if (!RES && !LAST) stage(kt + 1, st ^ 1);
 #endif
         const char* sK = smem + st * 2 * TILE;
         const char* sV = sK + TILE;
@@ -376,23 +384,63 @@ __global__ __launch_bounds__(256, NQT == 1 ? 4 : 2) void attn16_kernel(const cha
                 if constexpr (PLANES == 2) lacc[qt] = mma16<PLANES>(ones, pf[qt][pr][1], lacc[qt]);
                 lacc[qt] = mma16<PLANES>(ones, pf[qt][pr][0], lacc[qt]);
             }
-        fence();
+        if (!RES) fence();
     };
-    for (int kt = 0; kt + 1 < ntile; ++kt) tile(kt, std::false_type{});
-    tile(ntile - 1, std::true_type{});
-
+    auto finish = [&]() {
 #pragma unroll
-    for (int qt = 0; qt < NQT; ++qt) {
-        const float l = lacc[qt][0];  // every row of the tile holds the sum for query column fr
-        // split-f16: acc = sum (P * 2048) (V * 64); the output is written at the activation scale 64
-        const float inv = l > 0.f ? 1.0f / l : 0.f;  // split-f16: P and its row sum both carry the factor 2048
-        const int q = q0 + wave * QW + qt * 16 + fr;
+        for (int qt = 0; qt < NQT; ++qt) {
+            const float l = lacc[qt][0];  // every row of the tile holds the sum for query column fr
+            // split-f16: acc = sum (P * 2048) (V * 64); the output is written at the activation scale 64
+            const float inv = l > 0.f ? 1.0f / l : 0.f;  // split-f16: P and its row sum both carry the factor 2048
+            const int q = q0 + wave * QW + qt * 16 + fr;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const f32x4 v = o[qt][dt] * inv;
-            store_o(q, dt * 16 + fh * 4, v[0], v[1], v[2], v[3]);
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 v = o[qt][dt] * inv;
+                store_o(q, dt * 16 + fh * 4, v[0], v[1], v[2], v[3]);
+            }
         }
+    };
+    if constexpr (RES) {
+        // all K / V tiles of this (utterance, head) once, then query blocks of NW x QW queries without any further
+        // staging, fence or barrier; blocks wholly beyond the length write zeros (defined, finite output)
+        for (int kt = 0; kt < ntile; ++kt) stage(kt, kt);
+        fence();
+        for (q0 = 0; q0 < qlim; q0 += NW * QW) {
+            if (q0 + wave * QW >= len || ntile == 0) {
+#pragma unroll
+                for (int qt = 0; qt < NQT; ++qt)
+#pragma unroll
+                    for (int dt = 0; dt < 4; ++dt) store_o(q0 + wave * QW + qt * 16 + fr, dt * 16 + fh * 4, 0.f, 0.f, 0.f, 0.f);
+                continue;
+            }
+            load_q();
+            init_acc();
+            for (int kt = 0; kt + 1 < ntile; ++kt) tile(kt, std::false_type{});
+            tile(ntile - 1, std::true_type{});
+            finish();
+        }
+    } else {
+        load_q();
+        init_acc();
+        stage(0, 0);
+        fence();
+        for (int kt = 0; kt + 1 < ntile; ++kt) tile(kt, std::false_type{});
+        tile(ntile - 1, std::true_type{});
+        finish();
     }
+}
+
+#ifndef ATT_RES
+#define ATT_RES 0
+#endif
+// the K / V-resident form (bf16, T <= 512): one workgroup of 8 waves per (utterance, head), 128 KiB of LDS
+int launch16_resident(const void* qkv, void* out, const int32_t* lens, int B, int T, int H, const int32_t* row_start, hipStream_t s) {
+    constexpr int LDS = 8 * 2 * 64 * 128;
+    auto kern = attn16_kernel<1, 64, 2, true>;
+    SWC_ENABLE_LDS(kern, LDS, "swc_attention16");
+    dim3 grid(1, H, B), block(512);
+    hipLaunchKernelGGL(kern, grid, block, LDS, s, (const char*)qkv, (unsigned short*)out, lens, T, H, row_start);
+    return SWC_OK;
 }
 
 template <int PLANES, int KT16, int NQT>
@@ -420,7 +468,8 @@ extern "C" int swc_attention16(const void* qkv, void* out, const int32_t* lens, 
     // occupancy 3 -> 2) 56.2 us against 54.9; 16 queries per wave (91 registers, occupancy 5, but every K / V fragment
     // feeds half the MFMAs) 70.5 us against 56.0.  PMC (tools/pmc_attention.sh): the SIMDs spend 58 % of their cycles
     // issuing (VALU 46 %), matrix pipe 22 % busy, no LDS bank conflict: the kernel is bound by instructions per score.
-    int rc = dtype == SWC_BF16 ? launch16<1, 64, 2>(qkv, out, lens, B, T, H, row_start, (hipStream_t)stream)
+    int rc = dtype == SWC_BF16 ? ((ATT_RES && T <= 512) ? launch16_resident(qkv, out, lens, B, T, H, row_start, (hipStream_t)stream)
+                                                        : launch16<1, 64, 2>(qkv, out, lens, B, T, H, row_start, (hipStream_t)stream))
                                : launch16<2, 64, 2>(qkv, out, lens, B, T, H, row_start, (hipStream_t)stream);
     if (rc != SWC_OK) return rc;
     SWC_CHECK_LAUNCH("swc_attention16");
