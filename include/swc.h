@@ -257,6 +257,28 @@ int swc_layer_tail(const void* attn, const float* x, float* x_out, const void* w
                    void* stream);
 
 /*
+ * A split-f16 projection onto the residual stream with the LayerNorm behind it in one kernel — the `mixed` encoder's
+ * `x = x + out_proj(attn)` followed by final_layer_norm, and `x = x + fc2(h)` followed by the NEXT layer's
+ * self_attn_layer_norm (modules.py:214-232), where the two-launch form is swc_gemm (f32 output, residual) + swc_layernorm:
+ *     x_out[M][N]  = x + alpha * (A W^T) + bias          A: [M][lda >= K] split-f16 at SWC_F16S_ACT_SCALE, W: [N][K] split-f16
+ *     y_next[M][N] = LayerNorm(x_out; ln_w, ln_b, eps) as split-f16 at SWC_F16S_ACT_SCALE   (optional: y_next == NULL skips it)
+ * Three f16 MFMAs per product as in swc_gemm (hi*hi + hi*lo + lo*hi, f32 accumulation); the epilogue's element arithmetic is
+ * swc_gemm's and the LayerNorm's is swc_layernorm's, so y_next is bit-identical to swc_layernorm of the x_out this call stored
+ * (x_out itself differs from swc_gemm's in the last bits: another MFMA shape, another order of the k sum).  Clipping of y_next is
+ * counted (swc_set_saturation_counter).  Built for N = 768 and K % 64 == 0 (the shipped 768 / 3072); other geometries return
+ * SWC_E_ARG and the caller runs the two launches.  `w_stream`: W re-ordered ONCE at load by swc_proj_ln_pack into the order in
+ * which each wave consumes 1 KiB MFMA operand fragments (swc_proj_ln_stream_bytes(N, K) bytes, 0 for an unsupported geometry).
+ * x_out may be x.  lda in logical columns.
+ * Measured slower than the two launches at the path's shapes (profiles/r04_proj_ln_split_f16.txt: 85 / 222 us against 78 / 194 us at
+ * 16 000 tokens, K = 768 / 3072): AudioCodec does not call it; a caller with other shapes may.
+ */
+int64_t swc_proj_ln_stream_bytes(int32_t N, int32_t K);
+int swc_proj_ln_pack(const void* w_f16s, void* w_stream, int32_t N, int32_t K, void* stream);
+int swc_proj_ln(const void* a_f16s, int64_t lda, const void* w_stream, const float* bias, float alpha, const float* x,
+                float* x_out, const float* ln_w, const float* ln_b, float eps, void* y_next, int32_t M, int32_t N, int32_t K,
+                void* stream);
+
+/*
  * ConvNeXt front half: depthwise Conv1d(k=7, pad=3, groups=C) + LayerNorm(eps)
  * (modules.py:1233-1239).  x: [B][T][C] f32, w: [7][C], y: [B][T][C] (y_dtype).
  */

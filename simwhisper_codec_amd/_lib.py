@@ -79,10 +79,13 @@ SIGNATURES = {
     "swc_mlp_block": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "swc_layer_tail_pack": [_P, _P, _P, _P, _I, _I, _I, _P],
     "swc_layer_tail": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "swc_proj_ln_pack": [_P, _P, _I, _I, _P],
+    "swc_proj_ln": [_P, _L, _P, _P, _F, _P, _P, _P, _P, _F, _P, _I, _I, _I, _P],
 }
 PLAIN = {"swc_version": ([], C.c_int), "swc_last_error": ([], C.c_char_p), "swc_device_count": ([], C.c_int),
          "swc_convnext_stream_bytes": ([_I, _I], C.c_int64),
-         "swc_mlp_stream_bytes": ([_I, _I], C.c_int64), "swc_convnext64_stream_bytes": ([_I, _I], C.c_int64), "swc_layer_tail_stream_bytes": ([_I, _I, _I], C.c_int64)}
+         "swc_mlp_stream_bytes": ([_I, _I], C.c_int64), "swc_convnext64_stream_bytes": ([_I, _I], C.c_int64), "swc_layer_tail_stream_bytes": ([_I, _I, _I], C.c_int64),
+         "swc_proj_ln_stream_bytes": ([_I, _I], C.c_int64)}
 
 _lib = None
 

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libswc_hip.so")
-SOURCES = ["swc_api.hip", "swc_gemm.hip", "swc_attention.hip", "swc_attention16.hip", "swc_pointwise.hip", "swc_convnext.hip", "swc_mlp.hip", "swc_convnext64.hip"]
+SOURCES = ["swc_api.hip", "swc_gemm.hip", "swc_attention.hip", "swc_attention16.hip", "swc_pointwise.hip", "swc_convnext.hip", "swc_mlp.hip", "swc_convnext64.hip", "swc_projln.hip"]
 ARCH = "gfx950"
 # per-file flags.  -fno-slp-vectorize: hipcc otherwise packs adjacent f32 mul/add/fma into v_pk_*_f32, which issue at
 # half rate on gfx950 and cost extra v_mov shuffles — slower beside MFMAs (softmax, epilogues)
@@ -23,6 +23,7 @@ ARCH = "gfx950"
 _MAX_ILP = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 EXTRA_FLAGS = {"swc_attention16.hip": ["-fno-slp-vectorize"], "swc_convnext.hip": ["-fno-slp-vectorize"] + _MAX_ILP,
                "swc_mlp.hip": ["-fno-slp-vectorize"] + _MAX_ILP, "swc_convnext64.hip": ["-fno-slp-vectorize"] + _MAX_ILP,
+               "swc_projln.hip": ["-fno-slp-vectorize"] + _MAX_ILP,
                "swc_gemm.hip": _MAX_ILP}  # (-fno-slp-vectorize measured slower for swc_gemm.hip: -10 %)
 
 

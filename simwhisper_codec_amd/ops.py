@@ -482,6 +482,46 @@ def layer_tail(attn, x, w_stream, bo, ln_w, ln_b, eps, b1, b2, *, M, D, F, x_out
     return x_out, y_next
 
 
+def proj_ln_pack(w):
+    """A split-f16 weight [N, 2K] (fp16 tensor, SWC_F16S rows) on the device -> the operand stream of swc_proj_ln."""
+    lib = _lib.load()
+    _chk(w, "proj_ln_pack w", torch.float16)
+    N, K = w.shape[0], w.shape[1] // 2
+    n = lib.swc_proj_ln_stream_bytes(N, K)
+    if n <= 0:
+        raise _lib.SwcError(f"proj_ln_pack: unsupported geometry N={N} K={K}")
+    out = torch.empty(n, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.swc_proj_ln_pack(_ptr(w.contiguous()), _ptr(out), N, K, _stream()), "swc_proj_ln_pack")
+    return out
+
+
+def proj_ln(a, w_stream, bias, alpha, x, *, M, N, K, lda=None, x_out=None, ln=None, eps=1e-5, y_next=None):
+    """x_out = x + alpha * (a W^T) + bias (default: in place) and, with ln = (weight, bias), LayerNorm(x_out) as the split-f16
+    operand of the next GEMM (second return value) in one kernel (swc_proj_ln).  a: split-f16 [M, 2 lda]."""
+    lib = _lib.load()
+    _chk(a, "proj_ln a", torch.float16); _chk(x, "proj_ln x", torch.float32)
+    x_out = x if x_out is None else _chk(x_out, "proj_ln x_out", torch.float32)
+    lda = a.stride(-2) // 2 if lda is None else lda
+    if w_stream.numel() != lib.swc_proj_ln_stream_bytes(N, K):
+        raise _lib.SwcError(f"proj_ln: the operand stream ({w_stream.numel()} bytes) was not packed for N={N} K={K}")
+    lw = lb = None
+    if ln is not None:
+        lw, lb = ln
+        if y_next is None:
+            y_next = torch.empty((M, 2 * N), device=x.device, dtype=torch.float16)
+        _chk(y_next, "proj_ln y_next", torch.float16)
+    else:
+        y_next = None
+    prof = PROFILER
+    if prof is not None:
+        prof.begin("gemm_f16s", 2.0 * M * N * K)
+    _lib.check(lib.swc_proj_ln(_ptr(a), lda, _ptr(w_stream), _ptr(bias), float(alpha), _ptr(x), _ptr(x_out), _ptr(lw), _ptr(lb),
+                               float(eps), _ptr(y_next), M, N, K, _stream()), "swc_proj_ln")
+    if prof is not None:
+        prof.end()
+    return x_out, y_next
+
+
 def delay_us(us):
     """occupy the current stream for `us` microseconds (phase shift between two streams)"""
     _lib.check(_lib.load().swc_delay_us(int(us), _stream()), "swc_delay_us")

@@ -953,6 +953,77 @@ def test_layer_tail_fused(M, F_, with_next):
 
 
 
+@pytest.mark.parametrize("M,K,with_ln", [(64, 768, True), (300, 3072, True), (77, 768, False), (1000, 256, True),
+                                         (16000, 3072, True), (16000, 768, True)])
+def test_proj_ln_fused(M, K, with_ln):
+    """swc_proj_ln (split-f16 projection + bias + residual + LayerNorm -> split-f16 in one kernel: the `mixed` encoder's out-proj
+    and fc2 with the LayerNorm behind them, modules.py:214-232) vs (a) an f64 evaluation on the same split operands and (b) the
+    two launches it replaces (swc_gemm with an f32 output and a residual, swc_layernorm).  M covers partial 64-token tiles."""
+    ops = _ops()
+    N = 768
+    g = torch.Generator().manual_seed(M * 3 + K)
+    x0 = torch.randn(M, N, generator=g) * 1.5 + 0.1
+    A = torch.randn(M, K, generator=g) * 0.7
+    W = torch.randn(N, K, generator=g) * K ** -0.5
+    bias = torch.randn(N, generator=g) * 0.2
+    lw, lb = 1 + 0.2 * torch.randn(N, generator=g), 0.1 * torch.randn(N, generator=g)
+    d = lambda t: t.to(DEV)
+    sa, sw = 64.0, 2.0 ** 12
+    As, Ws = ops.cast_f16s(d(A), K, scale=sa), ops.cast_f16s(d(W), K, scale=sw)
+    alpha = 1.0 / (sa * sw)
+    stream = ops.proj_ln_pack(Ws)
+    x = d(x0).clone()
+    xo, y = ops.proj_ln(As, stream, d(bias), alpha, x, M=M, N=N, K=K, ln=(d(lw), d(lb)) if with_ln else None)
+    assert xo.data_ptr() == x.data_ptr() and torch.isfinite(xo).all()
+    # (b) the launches it replaces
+    x2 = d(x0).clone()
+    ops.gemm(As, Ws, M, N, K, bias=d(bias), alpha=alpha, residual=x2, out=x2)
+    # (a) f64 on the same operands
+    ref = x0.double() + _unsplit(As, K, sa) @ _unsplit(Ws, K, sw).T + bias.double()
+    scale = float((ref - x0.double()).abs().max())
+    e_ref = float((xo.cpu().double() - ref).abs().max()) / scale
+    e_two_ref = float((x2.cpu().double() - ref).abs().max()) / scale
+    assert e_ref < 2e-6, (e_ref, e_two_ref)                  # f32-class, like the GEMM it replaces
+    assert e_ref < 4 * e_two_ref + 2e-7, (e_ref, e_two_ref)
+    if with_ln:
+        want = ops.layernorm(xo, d(lw), d(lb), 1e-5, B=1, t_in=M, C_=N, out_dtype=torch.float16).view(M, 2 * N)
+        assert torch.equal(y, want)      # LayerNorm of the kernel's own x_out: the arithmetic of swc_layernorm, bit for bit
+    else:
+        assert y is None
+    # out of place: the input stream is read only, the result is the same bits; a wider A (lda > K) reads the same values
+    xin, out = d(x0).clone(), torch.full((M, N), float("nan"), device=DEV)
+    Aw = torch.zeros(M, 2 * (K + 64), dtype=torch.float16, device=DEV)
+    Aw[:, :2 * K] = As
+    ops.proj_ln(Aw, stream, d(bias), alpha, xin, M=M, N=N, K=K, lda=K + 64, x_out=out, ln=(d(lw), d(lb)) if with_ln else None)
+    assert torch.equal(xin.cpu(), x0) and torch.equal(out, xo)
+
+
+def test_proj_ln_errors_and_saturation():
+    ops = _ops()
+    from simwhisper_codec_amd._lib import SwcError
+    N, K, M = 768, 768, 64
+    Ws = ops.cast_f16s(torch.randn(N, K, device=DEV) * 0.03, K, scale=2.0 ** 12)
+    stream = ops.proj_ln_pack(Ws)
+    with pytest.raises(SwcError):
+        ops.proj_ln_pack(ops.cast_f16s(torch.randn(512, K, device=DEV), K, scale=64.0))          # N != 768
+    As = ops.cast_f16s(torch.randn(M, K, device=DEV), K, scale=64.0)
+    x = torch.zeros(M, N, device=DEV)
+    with pytest.raises(SwcError):
+        ops.proj_ln(As, stream, None, 1.0, x, M=M, N=N, K=3072)                                   # stream packed for another K
+    with pytest.raises(SwcError):
+        ops.proj_ln(As.cpu(), stream, None, 1.0, x, M=M, N=N, K=K)
+    # the LayerNorm output is counted when it leaves the split-f16 range: weight 2000 x scale 64 > 65504
+    cnt = torch.zeros(2, dtype=torch.int32, device=DEV)
+    ops.set_saturation_counter(cnt)
+    try:
+        big = torch.full((N,), 2000.0, device=DEV)
+        _, y = ops.proj_ln(As, stream, None, 2.0 ** -18, x, M=M, N=N, K=K, ln=(big, torch.zeros(N, device=DEV)))
+        torch.cuda.synchronize()
+        assert int(cnt[0]) > 0 and torch.isfinite(y.float()).all()
+    finally:
+        ops.set_saturation_counter(None)
+
+
 @pytest.mark.parametrize("M,F_", [(64, 256), (300, 512), (77, 256), (16000, 3072)])
 def test_layer_tail_fp8_fc1(M, F_):
     """swc_layer_tail with fc1 on the block-scaled fp8 MFMA (preset fp8_fc1): against (a) an f64 evaluation on the SAME quantised
