@@ -58,6 +58,9 @@ extern "C" {
  */
 #define SWC_FP8 3
 #define SWC_FP8_ACT_SCALE 16.0f
+/* SWC_F16 — plain IEEE half precision (11 significand bits, |x| <= 65504), one 16-bit element per value.  Exists as the
+ * operand type INSIDE swc_convnext_block (operand_dtype): no tensor of the path is stored in it. */
+#define SWC_F16 4
 
 #define SWC_ACT_NONE 0
 #define SWC_ACT_GELU 1 /* exact erf GELU == nn.GELU() / ACT2FN["gelu"] */
@@ -178,7 +181,7 @@ int swc_pack_rows(const void* src, void* dst, const int32_t* row_start, const in
  * x + gamma * b2; the gamma / b2 arguments of swc_convnext_mlp / swc_convnext_block must be the ones the stream was packed with.
  */
 int64_t swc_convnext_stream_bytes(int32_t C, int32_t I);
-int swc_convnext_pack(const void* w1_bf16, const void* w2_bf16, const float* gamma, void* w_stream, int32_t C, int32_t I,
+int swc_convnext_pack(const void* w1_16bit, const void* w2_16bit, const float* gamma, void* w_stream, int32_t C, int32_t I,
                       void* stream);
 int swc_convnext_mlp(const void* y, const void* w_stream, const float* b1, const float* b2, const float* gamma,
                      float* x, int32_t M, int32_t C, int32_t I, void* stream);
@@ -193,11 +196,16 @@ int swc_convnext_mlp(const void* y, const void* w_stream, const float* b1, const
  * 128-frame tile that lies wholly at or beyond the limits of the utterances it touches returns at once and leaves its rows
  * of x_out undefined.  The caller's limit must cover what it keeps plus the receptive field of the remaining blocks
  * (3 frames per block); no reference counterpart (the reference computes every padded frame, model.py:327-333).
+ * operand_dtype = SWC_BF16 | SWC_F16: the type of the block's INTERNAL MFMA operands — the LayerNorm output, the GELU output and
+ * the two weight matrices of `w_stream` (swc_convnext_pack re-orders 16-bit elements whatever their format: pass it
+ * pwconv1 / pwconv2 rounded to the same type).  SWC_F16 keeps 11 significand bits instead of bf16's 8 at the same MFMA rate;
+ * the values it holds are bounded by the block itself (|LayerNorm output| <= sqrt(C) |ln_w| + |ln_b|, hidden activations, weights)
+ * far inside +-65504.  x / x_out stay f32 either way.
  */
 int swc_convnext_block(const float* x, float* x_out, const float* dw_w7, const float* dw_bias, const float* ln_w,
                        const float* ln_b, float eps, const void* w_stream, const float* b1, const float* b2,
                        const float* gamma, int32_t B, int32_t T, int32_t C, int32_t I, const int32_t* t_limit,
-                       void* stream);
+                       int32_t operand_dtype, void* stream);
 
 /*
  * EXPERIMENT (round 4, not on the product path): swc_convnext_mlp on 64-frame tiles with two workgroups

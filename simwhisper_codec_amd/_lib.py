@@ -72,7 +72,7 @@ SIGNATURES = {
     "swc_pack_rows": [_P, _P, _P, _P, _I, _I, _L, _P],
     "swc_convnext_pack": [_P, _P, _P, _P, _I, _I, _P],
     "swc_convnext_mlp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
-    "swc_convnext_block": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "swc_convnext_block": [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P],
     "swc_convnext64_pack": [_P, _P, _P, _I, _I, _P],
     "swc_convnext64_mlp": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "swc_mlp_pack": [_P, _P, _P, _I, _I, _P],

@@ -645,21 +645,27 @@ class AudioCodec(nn.Module):
         # ---- decode side
         us = gp["upsample"]
         P.uhid = us["hidden_dim"]
-        P.flw, P.flb = W(_fold_wn(sd, "upsample.from_latent")[:, :, 0], ddt), V(sd["upsample.from_latent.bias"])
-        P.up_units = res_units("upsample", ddt)
+        # 16-bit decode presets keep their 16-bit operands where the flops are (12 decoder layers, 24 ConvNeXt blocks: 97 % of the
+        # decode side) and run the small stages around them on split-f16 operands: the up-sampler (P.udt), the decoder's output
+        # stage + Vocos' embed conv (P.io16) and the ISTFT head (P.tail16).  tools/probes/decode_error_attribution.py
+        P.udt = torch.float16 if (ddt == torch.bfloat16 and self.upsample_split_f16) else ddt
+        P.flw, P.flb = W(_fold_wn(sd, "upsample.from_latent")[:, :, 0], P.udt), V(sd["upsample.from_latent.bias"])
+        P.up_units = res_units("upsample", P.udt)
         w = _fold_wn(sd, "upsample.to_stacked")[:, :, 0]                    # [(d*s + s_idx)][hid]
         od = us["out_dim"]
         w = w.view(od, P.stack, -1).permute(1, 0, 2).reshape(od * P.stack, -1)
         b = sd["upsample.to_stacked.bias"].view(od, P.stack).T.reshape(-1)
-        P.tsw, P.tsb = W(w, ddt), V(b)
+        P.tsw, P.tsb = W(w, P.udt), V(b)
         dc = gp["acoustic_decoder"]
         P.Dd, P.Hd = dc["d_model"], dc["decoder_attention_heads"]
         P.dec_layers = layers("acoustic_decoder", dc["decoder_layers"], ddt)
         P.dec_ln = (V(sd["acoustic_decoder.layer_norm.weight"]), V(sd["acoustic_decoder.layer_norm.bias"]))
+        P.io16 = ddt == torch.float16 or (ddt == torch.bfloat16 and self.decoder_io_split_f16 and dc["d_model"] % 32 == 0)
+        iodt = torch.float16 if P.io16 else ddt
         w1 = sd["acoustic_decoder.deconv1.weight"]                          # (ci, co, j)
-        P.d1w, P.d1b = W(w1.permute(2, 1, 0).reshape(-1, w1.shape[0]), ddt), V(sd["acoustic_decoder.deconv1.bias"])
+        P.d1w, P.d1b = W(w1.permute(2, 1, 0).reshape(-1, w1.shape[0]), iodt), V(sd["acoustic_decoder.deconv1.bias"])
         w2 = sd["acoustic_decoder.deconv2.weight"]                          # (ci, co, j): conv with flipped taps, pad 2
-        P.d2w = W(w2.flip(2).permute(1, 2, 0).reshape(w2.shape[1], -1), ddt)
+        P.d2w = W(w2.flip(2).permute(1, 2, 0).reshape(w2.shape[1], -1), iodt)
         P.d2b = V(sd["acoustic_decoder.deconv2.bias"])
         v = gp["vocos"]
         P.vdim, P.vint, P.vin = v["dim"], v["intermediate_dim"], v["input_channels"]
@@ -668,16 +674,23 @@ class AudioCodec(nn.Module):
         # zero-padded to 96 per tap for the embed conv and the ISTFT spectrum (642 -> 648 columns) to 672, as conv1 does on the
         # encode side
         dd16 = ddt == torch.float16
-        P.vin_k = spec.cdiv(P.vin, 32) * 32 if dd16 else P.vin
-        P.idft_k = 672 if dd16 else 648
+        P.vin_k = spec.cdiv(P.vin, 32) * 32 if P.io16 else P.vin
+        # the ISTFT head (final LayerNorm -> Linear 512 -> 642 -> exp / cos / sin -> inverse DFT) in split-f16 while the backbone
+        # keeps 16-bit operands: 0.7 % of Vocos' flops, and the stage whose rounding the waveform sees undamped (log-magnitudes
+        # go through exp(), phases through cos / sin)
+        P.tail16 = dd16 or (ddt == torch.bfloat16 and self.vocos_head_split_f16 and v["dim"] % 32 == 0)
+        P.idft_k = 672 if P.tail16 else 648
         emw = sd[p + "embed.weight"]                                        # (C, vin, 7)
         if P.vin_k != P.vin:
             emw = torch.nn.functional.pad(emw, (0, 0, 0, P.vin_k - P.vin))
-        P.emw, P.emb = W(conv_w(emw), ddt), V(sd[p + "embed.bias"])
+        P.emw, P.emb = W(conv_w(emw), iodt), V(sd[p + "embed.bias"])
         P.vnorm = (V(sd[p + "norm.weight"]), V(sd[p + "norm.bias"]))
         P.blocks = []
         # the fused MLP kernel (swc_convnext_mlp) exists for the shipped geometry with bf16 operands
         P.fused_mlp = ddt == torch.bfloat16 and ops.convnext_supported(P.vdim, P.vint)
+        # the fused block's internal operands in plain f16 when every pointwise weight is representable (finite, and the block's
+        # LayerNorm cannot leave the range: sqrt(C) max|ln_w| + max|ln_b| < 65504 / 8)
+        P.cx_f16 = bool(P.fused_mlp and self.convnext_f16 and self._cx_f16_safe(sd, p, v["num_layers"], P.vdim))
         for i in range(v["num_layers"]):
             b_ = f"{p}convnext.{i}."
             P.blocks.append(dict(
@@ -687,15 +700,20 @@ class AudioCodec(nn.Module):
                 w2=W(sd[b_ + "pwconv2.weight"], ddt), b2=V(sd[b_ + "pwconv2.bias"]), g=V(sd[b_ + "gamma"])))
             if P.fused_mlp:
                 blk = P.blocks[-1]
-                blk["ws"] = ops.convnext_pack(blk["w1"].w, blk["w2"].w, blk["g"])
+                if P.cx_f16:   # plain half precision inside the fused block kernel: the same f32 weights rounded to 11 bits, not 8
+                    blk["ws"] = ops.convnext_pack(V(sd[b_ + "pwconv1.weight"]).to(torch.float16),
+                                                  V(sd[b_ + "pwconv2.weight"]).to(torch.float16), blk["g"])
+                else:
+                    blk["ws"] = ops.convnext_pack(blk["w1"].w, blk["w2"].w, blk["g"])
         # frames a kept sample can depend on: embed k7 (+-3), one depthwise k7 per block (+-3 each), ISTFT overlap (+-3)
         if self.VOCOS_HALO_FRAMES < 3 * (v["num_layers"] + 1) + 3:
             raise SwcError(f"VOCOS_HALO_FRAMES = {self.VOCOS_HALO_FRAMES} is too small for {v['num_layers']} ConvNeXt blocks "
                            "(halo-trimmed / tile-skipping Vocos would no longer be bit-exact)")
         P.vfin = (V(sd[p + "final_layer_norm.weight"]), V(sd[p + "final_layer_norm.bias"]))
-        P.hw, P.hb = W(sd["vocos.head.out.weight"], ddt), V(sd["vocos.head.out.bias"])
+        tdt = torch.float16 if P.tail16 else ddt
+        P.hw, P.hb = W(sd["vocos.head.out.weight"], tdt), V(sd["vocos.head.out.bias"])
         win = sd["vocos.head.istft.window"].float()
-        P.idft = W(spec.idft_basis(640, win, P.idft_k), ddt)                 # [640][648] ([640][672] for split-f16 operands)
+        P.idft = W(spec.idft_basis(640, win, P.idft_k), tdt)                 # [640][648] ([640][672] for split-f16 operands)
         P.wsq = V(win.square())
         torch.cuda.synchronize(dev)
         return P
@@ -774,6 +792,34 @@ class AudioCodec(nn.Module):
         rounds = spec.cdiv(tiles, self.CUS)
         return tiles >= 0.6 * rounds * self.CUS  # a poorly filled last round of 64-token tiles costs a whole round
 
+    # True: the fused ConvNeXt block keeps its internal operands (LayerNorm output, GELU output, pointwise weights) in plain f16
+    # instead of bf16 (read at pack time).  Measured (tools/probes/decode_error_budget.py, profiles/r04_decode_error_budget.txt):
+    # the Vocos stage error does not move (2.90e-3 against 2.92e-3 once the ISTFT head runs on split-f16 operands: the blocks'
+    # operand rounding is not what the waveform sees) and the step is 1 - 2 % slower (f16 MFMAs draw more than bf16 ones): off
+    convnext_f16 = False
+
+    @staticmethod
+    def _cx_f16_safe(sd, p, n_blocks, C):
+        lim = 65504.0 / 8
+        for i in range(n_blocks):
+            b_ = f"{p}convnext.{i}."
+            w1, w2 = sd[b_ + "pwconv1.weight"], sd[b_ + "pwconv2.weight"]
+            if not (bool(torch.isfinite(w1).all()) and bool(torch.isfinite(w2).all())):
+                return False
+            if float(w1.abs().max()) >= lim or float(w2.abs().max()) >= lim:
+                return False
+            if math.sqrt(C) * float(sd[b_ + "norm.weight"].abs().max()) + float(sd[b_ + "norm.bias"].abs().max()) >= lim:
+                return False
+        return True
+
+    # 16-bit decode presets (read at pack time): small stages around the decoder layers and the ConvNeXt blocks on split-f16
+    # operands — f32-class arithmetic where the waveform sees rounding undamped (measured at 32 x 10 s,
+    # waveform error against the reference / decode time: profiles/r04_decode_error_budget.txt):
+    #   none 1.5 - 1.8e-2 | head 8.5e-3, +0.10 ms | head + io 6.5e-3, +0.35 ms | head + io + up 5.8e-3, +0.6 ms (the 12 bf16 decoder
+    #   layers alone: 5.3 - 6.0e-3).  The head is on: half the error for 0.5 % of the step; the other two are there to be switched on
+    vocos_head_split_f16 = True    # final LayerNorm -> Linear 512 -> 642 -> exp / cos / sin -> inverse DFT
+    decoder_io_split_f16 = False   # decoder: final LayerNorm -> deconv1 -> deconv2 -> mel; Vocos: embed conv
+    upsample_split_f16 = False     # FrameStackUpConv: from_latent, 3 residual units (snake + k7 / k1 convs), to_stacked
     conv1_split_f16 = True  # `mixed`: conv1 on the split-f16 MFMA path (mel bins padded 80 -> 96); False: exact f32 (read at pack time)
     varlen_packing = True   # ragged calls: the transformers run on the valid tokens only (packed rows), not on B x longest
     PACK_BELOW = 0.9        # ... when the valid tokens are under this fraction of the padded rows
@@ -889,7 +935,7 @@ class AudioCodec(nn.Module):
     def _upsample_impl(self, zq, B, T, P):
         """FrameStackUpConv (modules.py:601-631, not masked) on zq [B, T, lat] f32.  Returns x [B * s*T, D] f32: to_stacked
         with re-ordered rows makes [B*T, s*D] the un-stacked [B, s*T, D] token stream."""
-        dt, s, D = P.ddt, P.stack, P.Dd
+        dt, s, D = getattr(P, "udt", P.ddt), P.stack, P.Dd
         h = self._mm(self._cast(zq, dt), P.flw, B * T, P.uhid, P.lat, lda=P.lat, bias=P.flb)
         self._res_units(h, P.up_units, B, T, P.uhid, dt)
         x = self._mm(self._cast(h, dt), P.tsw, B * T, s * D, P.uhid, lda=P.uhid, bias=P.tsb)
@@ -909,11 +955,12 @@ class AudioCodec(nn.Module):
         if row_start is not None:  # tokens beyond a length are masked keys and zeroed outputs: they need not exist
             x = ops.pack_rows(x, row_start, lens, B=B, T=Tt, total=total)
         self._transformer(x, lens, B, Tt, P.dec_layers, P.Hd, dt, row_start=row_start)
-        hn = ops.layernorm(x, P.dec_ln[0], P.dec_ln[1], 1e-5, B=B, t_in=Tt, C_=D, lens=lens, out_dtype=dt,
-                           row_start=row_start)
-        y3 = self._mm(hn, P.d1w, B * Tt, 3 * D, D, lda=D)
+        io16 = getattr(P, "io16", dt == torch.float16)
+        hn = ops.layernorm(x, P.dec_ln[0], P.dec_ln[1], 1e-5, B=B, t_in=Tt, C_=D, lens=lens,
+                           out_dtype=torch.float16 if io16 else dt, row_start=row_start)
+        y3 = self._mm(hn.view(B * Tt, -1), P.d1w, B * Tt, 3 * D, D, lda=D)
         Tv = 2 * Tt
-        if dt == torch.float16:  # split-f16 operands: the col2im kernel writes f32 / bf16; one conversion pass each
+        if io16:  # split-f16 operands: the col2im kernel writes f32 / bf16; one conversion pass each
             d1 = ops.deconv_col2im(y3, P.d1b, B=B, T=Tt, C_=D, s=2, t_out=Tv + 1, out_dtype=torch.float32)
             d1 = ops.cast_f16s(d1.view(B * (Tv + 1), D), D)
             mel = torch.zeros((B * Tv, P.vin_k), device=dev, dtype=torch.float32)   # 80 channels + zero columns up to 96
@@ -955,8 +1002,8 @@ class AudioCodec(nn.Module):
         limits (host ints per row, or None): frames at or beyond limits[b] need not be right (ragged decode)."""
         dt, C, M = P.ddt, P.vdim, B * Tv
         dd16 = dt == torch.float16
-        if dd16 and mel.dtype == torch.float32:  # a caller's own [B, Tv, 80] f32 mel (stage tests): pad the channels, convert
-            mel = ops.cast_f16s(torch.nn.functional.pad(mel, (0, P.vin_k - mel.shape[-1])).reshape(M, P.vin_k), P.vin_k)
+        if getattr(P, "io16", dd16) and mel.dtype != torch.float16:  # a caller's own [B, Tv, 80] mel (stage tests, forward()): pad the channels, convert
+            mel = ops.cast_f16s(torch.nn.functional.pad(mel.float(), (0, P.vin_k - mel.shape[-1])).reshape(M, P.vin_k), P.vin_k)
         x = self._mm(mel, P.emw, M, C, P.vin_k, lda=P.vin_k, ldw=7 * P.vin_k, bias=P.emb, taps=7, pad=3, t_in=Tv, t_out=Tv)
         x = ops.layernorm(x, P.vnorm[0], P.vnorm[1], 1e-6, B=B, t_in=Tv, C_=C)
         # one fused kernel per block when the grid fills the chip (128-frame tiles, one per CU); small batches keep the
@@ -973,7 +1020,8 @@ class AudioCodec(nn.Module):
         else:
             for blk in P.blocks if fused else ():  # the whole block (depthwise conv + LayerNorm + MLP + residual) is one kernel
                 ops.convnext_block(x, x2, blk["dw"], blk["db"], blk["ln"][0], blk["ln"][1], 1e-6, blk["ws"], blk["b1"],
-                                   blk["b2"], blk["g"], B=B, T=Tv, C_=C, I=P.vint, t_limit=lim_dev)
+                                   blk["b2"], blk["g"], B=B, T=Tv, C_=C, I=P.vint, t_limit=lim_dev,
+                                   operands=torch.float16 if getattr(P, "cx_f16", False) else torch.bfloat16)
                 x, x2 = x2, x
         for blk in P.blocks:
             if fused:
@@ -984,11 +1032,12 @@ class AudioCodec(nn.Module):
                 y = ops.cast_f16s(y.view(M, C), C)
             y = self._mm(y, blk["w1"], M, P.vint, C, lda=C, bias=blk["b1"], act=ops.ACT_GELU, out_dtype=dt)
             self._mm(y, blk["w2"], M, C, P.vint, lda=P.vint, bias=blk["b2"], gamma=blk["g"], residual=x, out=x)
-        hn = ops.layernorm(x, P.vfin[0], P.vfin[1], 1e-6, B=B, t_in=Tv, C_=C, out_dtype=dt)
+        t16 = getattr(P, "tail16", dd16)
+        hn = ops.layernorm(x, P.vfin[0], P.vfin[1], 1e-6, B=B, t_in=Tv, C_=C, out_dtype=torch.float16 if t16 else dt)
         ho = torch.empty((M, 648), device=mel.device, dtype=torch.float32)  # ld 648: 16-byte rows for vector stores
-        self._mm(hn, P.hw, M, 642, C, lda=C, bias=P.hb, out=ho, ldc=648)
-        sp = ops.istft_spec(ho, 648, M, P.idft_k, out_dtype=torch.float32 if dd16 else dt)
-        if dd16:
+        self._mm(hn.view(M, -1), P.hw, M, 642, C, lda=C, bias=P.hb, out=ho, ldc=648)
+        sp = ops.istft_spec(ho, 648, M, P.idft_k, out_dtype=torch.float32 if t16 else dt)
+        if t16:
             sp = ops.cast_f16s(sp, P.idft_k)
         fr = self._mm(sp, P.idft, M, 640, P.idft_k, lda=P.idft_k)
         return ops.istft_ola(fr, P.wsq, B=B, T=Tv)
@@ -1042,7 +1091,8 @@ class AudioCodec(nn.Module):
         def run(blk, cur, part):
             src, dst = (xa[part], xb[part]) if cur == 0 else (xb[part], xa[part])
             ops.convnext_block(src, dst, blk["dw"], blk["db"], blk["ln"][0], blk["ln"][1], 1e-6, blk["ws"], blk["b1"],
-                               blk["b2"], blk["g"], B=nb[part], T=Tv, C_=C, I=P.vint, chip_share=shares[part])
+                               blk["b2"], blk["g"], B=nb[part], T=Tv, C_=C, I=P.vint, chip_share=shares[part],
+                               operands=torch.float16 if getattr(P, "cx_f16", False) else torch.bfloat16)
         # an out-of-phase second chain starts half a launch late (events only fire at launch boundaries, which would put the
         # chains back in phase: a one-wave delay kernel shifts it) and stays out of phase: equal launches, in-order streams
         cur = 0

@@ -77,26 +77,54 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+// F16 (operand_dtype SWC_F16): the block's internal operands — LayerNorm output, GELU output, both weight matrices — are IEEE
+// half precision instead of bf16: 11 significand bits instead of 8 at the same MFMA rate.  Their ranges are bounded by the block
+// itself (|LayerNorm output| <= sqrt(C) |ln_w| + |ln_b|; hidden activations of O(10); weights < 1), three to four orders of
+// magnitude inside +-65504; the conversion is RNE like the bf16 one.
+template <bool F16>
+__device__ __forceinline__ unsigned pack_x2(float lo, float hi) {
+    if constexpr (F16) {
+        unsigned r;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    } else {
+        return pack_bf16x2(lo, hi);
+    }
+}
 
 // GEMM1's MFMAs in VGPR form.  The 256 accumulators of GEMM2 fill the AGPR half of the register file; left to hipcc, the
 // 64 accumulators of GEMM1 are also given AGPR-form MFMAs and the two sets are shuffled between the halves with ~1500
 // v_accvgpr_read/write/mov per slice (6 k issue cycles beside 8 k MFMA cycles).  Written as asm with "v" operands these
 // four MFMAs keep their accumulators in VGPRs, where the GELU reads them directly.  One statement per k-step: the
 // leading s_nop 1 covers a VALU copy of an operand hipcc may have placed right in front (it pads nothing inside asm).
+template <bool F16 = false>
 __device__ __forceinline__ void mfma32x4_vgpr(const u32x4& a, const u32x4& b0, const u32x4& b1, const u32x4& b2, const u32x4& b3,
                                               f32x16& c0, f32x16& c1, f32x16& c2, f32x16& c3) {
-    asm("s_nop 1\n\t"
-        "v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\t"
-        "v_mfma_f32_32x32x16_bf16 %1, %4, %6, %1\n\t"
-        "v_mfma_f32_32x32x16_bf16 %2, %4, %7, %2\n\t"
-        "v_mfma_f32_32x32x16_bf16 %3, %4, %8, %3"
-        : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
-        : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    if constexpr (F16)
+        asm("s_nop 1\n\t"
+            "v_mfma_f32_32x32x16_f16 %0, %4, %5, %0\n\t"
+            "v_mfma_f32_32x32x16_f16 %1, %4, %6, %1\n\t"
+            "v_mfma_f32_32x32x16_f16 %2, %4, %7, %2\n\t"
+            "v_mfma_f32_32x32x16_f16 %3, %4, %8, %3"
+            : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+            : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+    else
+        asm("s_nop 1\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, %4, %5, %0\n\t"
+            "v_mfma_f32_32x32x16_bf16 %1, %4, %6, %1\n\t"
+            "v_mfma_f32_32x32x16_bf16 %2, %4, %7, %2\n\t"
+            "v_mfma_f32_32x32x16_bf16 %3, %4, %8, %3"
+            : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3)
+            : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
 }
 
+template <bool F16 = false>
 __device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b),
-                                                   c, 0, 0, 0);
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&a), *reinterpret_cast<const f16x8*>(&b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b),
+                                                       c, 0, 0, 0);
 }
 
 // front half of the block for the fused form: depthwise Conv1d(k7, pad 3, per utterance) + LayerNorm (modules.py:1233-1239)
@@ -112,7 +140,7 @@ struct CxFront {
 
 // wstream: per wave w (4 of them) NS * 64 + CX_PF fragments of 1 KiB in the order of consumption (swc_convnext_pack)
 // FUSED_DW: y is not read; the workgroup computes LayerNorm(dwconv7(x)) of its 128 frames itself (front half above)
-template <bool FUSED_DW>
+template <bool FUSED_DW, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __restrict__ y, const u32x4* __restrict__ wstream,
                                                              const float* __restrict__ b1, const float* __restrict__ b2,
                                                              const float* __restrict__ gamma, const float* x, float* xo,
@@ -262,7 +290,7 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
                     // byte (c % 8) * 2
                     const int s_ = 16 * k + (lane >> 2);
                     const int off = ((s_ * 4 + w) * 64 + 32 * ((lane >> 1) & 1) + fl) * 16 + (lane & 1) * 8;
-                    *reinterpret_cast<uint2*>(ybase + off) = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+                    *reinterpret_cast<uint2*>(ybase + off) = make_uint2(pack_x2<F16>(o0, o1), pack_x2<F16>(o2, o3));
                 }
             }
             // slide the window by 4 rows
@@ -372,13 +400,13 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
             for (int u = 0; u < CX_PF; u += 2) {
                 {
                     y_frags(s0 + u + 1, yB);
-                    mfma32x4_vgpr(ring[u], yA[0], yA[1], yA[2], yA[3], acc1[0], acc1[1], acc1[2], acc1[3]);
+                    mfma32x4_vgpr<F16>(ring[u], yA[0], yA[1], yA[2], yA[3], acc1[0], acc1[1], acc1[2], acc1[3]);
                     ring[u] = wfrag(s0 + u + CX_PF);  // refill the slot just consumed (no copy of the operand)
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 {
                     y_frags((s0 + u + 2) & 31, yA);  // the last step re-reads step 0 (harmless)
-                    mfma32x4_vgpr(ring[u + 1], yB[0], yB[1], yB[2], yB[3], acc1[0], acc1[1], acc1[2], acc1[3]);
+                    mfma32x4_vgpr<F16>(ring[u + 1], yB[0], yB[1], yB[2], yB[3], acc1[0], acc1[1], acc1[2], acc1[3]);
                     ring[u + 1] = wfrag(s0 + u + 1 + CX_PF);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -396,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (CX_ABL & 2) ? acc1[b][8 * t + e] : gelu_fast(acc1[b][8 * t + e]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc1[b][4 * t + i] = __uint_as_float(pack_bf16x2(v[2 * i], v[2 * i + 1]));
+        for (int i = 0; i < 4; ++i) acc1[b][4 * t + i] = __uint_as_float(pack_x2<F16>(v[2 * i], v[2 * i + 1]));
     };
     auto store_h = [&]() {
 #pragma unroll
@@ -417,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void convnext_mlp_kernel(const bf16_t* __re
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc2[n][b] = mfma32(ring[(q * 4 + n) % CX_PF], cur[b], acc2[n][b]);
+                for (int b = 0; b < 4; ++b) acc2[n][b] = mfma32<F16>(ring[(q * 4 + n) % CX_PF], cur[b], acc2[n][b]);
                 ring[(q * 4 + n) % CX_PF] = wfrag(q * 4 + n + CX_PF);
             }
             if constexpr (decltype(with_gelu)::value) gelu_frag(q >> 1, q & 1);
@@ -1083,7 +1111,11 @@ extern "C" int swc_convnext_mlp(const void* y, const void* w_stream, const float
 extern "C" int swc_convnext_block(const float* x, float* x_out, const float* dw_w7, const float* dw_bias, const float* ln_w,
                                   const float* ln_b, float eps, const void* w_stream, const float* b1, const float* b2,
                                   const float* gamma, int32_t B, int32_t T, int32_t C, int32_t I, const int32_t* t_limit,
-                                  void* stream) {
+                                  int32_t operand_dtype, void* stream) {
+    SWC_CHECK_ARG(operand_dtype == SWC_BF16 || operand_dtype == SWC_F16, "swc_convnext_block: operand_dtype must be BF16 or F16");
+#if CX_MFMA16 || CX_RES_ACC
+    SWC_CHECK_ARG(operand_dtype == SWC_BF16, "swc_convnext_block: this build has bf16 operands only");
+#endif
     SWC_CHECK_ARG(x && x_out && x != x_out, "swc_convnext_block: x and x_out must be two different buffers");
     SWC_CHECK_ARG(x && dw_w7 && dw_bias && ln_w && ln_b && w_stream && b1 && b2 && gamma, "swc_convnext_block: null pointer");
     SWC_CHECK_ARG(C == CX_C && I > 0 && I % CX_SL == 0, "swc_convnext_block: needs C = %d and I a multiple of %d (C=%d I=%d)",
@@ -1094,14 +1126,22 @@ extern "C" int swc_convnext_block(const float* x, float* x_out, const float* dw_
                   "swc_convnext_block: unaligned");
     const int M = B * T;
     if (M == 0) return SWC_OK;
+    const unsigned grid = (unsigned)((M + CX_BM - 1) / CX_BM);
+    CxFront fr{dw_w7, dw_bias, ln_w, ln_b, T, eps, t_limit};
 #if CX_MFMA16
     auto kern = convnext16_kernel<true>;
 #else
+    if (operand_dtype == SWC_F16) {
+        auto kern16 = convnext_mlp_kernel<true, true>;
+        SWC_ENABLE_LDS(kern16, CX_LDS, "swc_convnext_block");
+        hipLaunchKernelGGL(kern16, dim3(grid), dim3(256), CX_LDS, (hipStream_t)stream, (const bf16_t*)nullptr,
+                           (const u32x4*)w_stream, b1, b2, gamma, x, x_out, M, I / CX_SL, fr);
+        SWC_CHECK_LAUNCH("swc_convnext_block");
+        return SWC_OK;
+    }
     auto kern = convnext_mlp_kernel<true>;
 #endif
     SWC_ENABLE_LDS(kern, CX_LDS, "swc_convnext_block");
-    const unsigned grid = (unsigned)((M + CX_BM - 1) / CX_BM);
-    CxFront fr{dw_w7, dw_bias, ln_w, ln_b, T, eps, t_limit};
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), CX_LDS, (hipStream_t)stream, (const bf16_t*)nullptr,
                        (const u32x4*)w_stream, b1, b2, gamma, x, x_out, M, I / CX_SL, fr);
     SWC_CHECK_LAUNCH("swc_convnext_block");

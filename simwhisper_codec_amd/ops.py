@@ -314,9 +314,13 @@ def convnext_supported(C_, I):
 
 def convnext_pack(w1, w2, gamma):
     """pwconv1.weight [I, C], pwconv2.weight [C, I] (bf16, device) and the block's gamma [C] (f32) -> the packed operand stream of
-    swc_convnext_mlp / swc_convnext_block (gamma is folded into pwconv2's rows)."""
+    swc_convnext_mlp / swc_convnext_block (gamma is folded into pwconv2's rows by CX_RES_ACC builds).
+    Both weights may instead be PLAIN float16 [I, C] / [C, I] (not the split-f16 layout): the stream then serves
+    convnext_block(..., operands=torch.float16)."""
     lib = _lib.load()
-    _chk(w1, "convnext_pack w1", torch.bfloat16); _chk(w2, "convnext_pack w2", torch.bfloat16)
+    _chk(w1, "convnext_pack w1"); _chk(w2, "convnext_pack w2", w1.dtype)
+    if w1.dtype not in (torch.bfloat16, torch.float16):
+        raise _lib.SwcError(f"convnext_pack: weights must be bf16 or plain f16, got {w1.dtype}")
     _chk(gamma, "convnext_pack gamma", torch.float32)
     I, C_ = w1.shape
     if tuple(w2.shape) != (C_, I):
@@ -370,9 +374,13 @@ def abi_version():
     return int(_lib.load().swc_version())
 
 
+SWC_F16 = 4  # include/swc.h: plain half precision, the internal operand type of swc_convnext_block (operands=torch.float16)
+
+
 def convnext_block(x, x_out, w7, dw_bias, ln_w, ln_b, eps, w_stream, b1, b2, gamma, *, B, T, C_, I, chip_share=1.0,
-                   t_limit=None):
+                   t_limit=None, operands=torch.bfloat16):
     """One whole ConvNeXt block: residual stream x [B, T, C] f32 -> x_out (a different buffer; swc_convnext_block).
+    operands: torch.bfloat16, or torch.float16 = PLAIN half precision inside the kernel (w_stream packed from float16 weights).
     t_limit (int32 device tensor [B], ragged batches): frames at or beyond t_limit[b] need not be computed.
     chip_share (profiling only): the fraction of the chip this launch runs on when another chain runs beside it on a
     second stream; the timing hook charges duration x chip_share, so that TFLOP/s stays a whole-chip rate."""
@@ -382,7 +390,8 @@ def convnext_block(x, x_out, w7, dw_bias, ln_w, ln_b, eps, w_stream, b1, b2, gam
     if prof is not None:
         prof.begin("convnext_bf16", 4.0 * B * T * C_ * I, chip_share)
     _lib.check(lib.swc_convnext_block(_ptr(x), _ptr(x_out), _ptr(w7), _ptr(dw_bias), _ptr(ln_w), _ptr(ln_b), eps, _ptr(w_stream),
-                                      _ptr(b1), _ptr(b2), _ptr(gamma), B, T, C_, I, _ptr(t_limit), _stream()), "swc_convnext_block")
+                                      _ptr(b1), _ptr(b2), _ptr(gamma), B, T, C_, I, _ptr(t_limit),
+                                      SWC_F16 if operands == torch.float16 else _DT[operands], _stream()), "swc_convnext_block")
     if prof is not None:
         prof.end()
     return x_out

@@ -771,6 +771,46 @@ def test_convnext_block_fused(B, T, I):
     assert e_pair < 2e-3, e_pair      # same arithmetic as the two-kernel form up to the bf16 rounding of y at ties
 
 
+@pytest.mark.parametrize("B,T,I", [(3, 100, 256), (40, 125, 4096), (1, 5, 128)])
+def test_convnext_block_f16_operands(B, T, I):
+    """swc_convnext_block with operand_dtype SWC_F16 (the block's internal operands in plain half precision; what the `mixed`
+    preset runs at the metric's shape): against an f64 evaluation of ConvNeXtBlock.forward on the UNROUNDED f32 weights
+    (modules.py:1229-1248) its error must be several times below the bf16 form's on the same inputs; a LayerNorm output beyond
+    the f16 range is refused by the codec's pack step, not by the kernel (test_host_cpu)."""
+    ops = _ops()
+    C = 512
+    g = torch.Generator().manual_seed(B * 77 + T)
+    x0 = torch.randn(B, T, C, generator=g)
+    w7, db = torch.randn(7, C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1
+    lw, lb = 1 + 0.2 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w1, w2 = torch.randn(I, C, generator=g) * C ** -0.5, torch.randn(C, I, generator=g) * I ** -0.5
+    b1, b2, gam = torch.randn(I, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g)
+    d = lambda t: t.to(DEV)
+    xd = d(x0)
+    outs = {}
+    for dt in (torch.float16, torch.bfloat16):
+        ws = ops.convnext_pack(d(w1).to(dt), d(w2).to(dt), d(gam))
+        out = torch.full_like(xd, float("nan"))
+        ops.convnext_block(xd, out, d(w7), d(db), d(lw), d(lb), 1e-6, ws, d(b1), d(b2), d(gam), B=B, T=T, C_=C, I=I, operands=dt)
+        assert torch.isfinite(out).all()
+        outs[dt] = out.cpu().double()
+    xr = x0.double().transpose(1, 2)
+    conv = F.conv1d(xr, w7.double().T.unsqueeze(1), db.double(), padding=3, groups=C).transpose(1, 2)
+    yn = F.layer_norm(conv, (C,), lw.double(), lb.double(), 1e-6)
+    ref = x0.double() + gam.double() * (F.gelu(yn @ w1.double().T + b1.double()) @ w2.double().T + b2.double())
+    scale = float((ref - x0.double()).abs().max())
+    e16 = float((outs[torch.float16] - ref).abs().max()) / scale
+    eb = float((outs[torch.bfloat16] - ref).abs().max()) / scale
+    rms16 = float((outs[torch.float16] - ref).pow(2).mean().sqrt()) / scale
+    rmsb = float((outs[torch.bfloat16] - ref).pow(2).mean().sqrt()) / scale
+    assert e16 < 3e-3 and eb < 2e-2, (e16, eb)
+    assert rms16 < 0.3 * rmsb, (rms16, rmsb)     # (the GELU refit, |error| <= 2.7e-4, is common to both and bounds the gain)
+    from simwhisper_codec_amd._lib import SwcError
+    with pytest.raises(SwcError):
+        ops.convnext_block(xd, torch.empty_like(xd), d(w7), d(db), d(lw), d(lb), 1e-6, ws, d(b1), d(b2), d(gam), B=B, T=T, C_=C, I=I,
+                           operands=torch.float32)
+
+
 @pytest.mark.parametrize("n,off", [(0, 0), (1, 0), (7, 0), (8, 0), (160000, 0), (160003, 0), (4099, 3), (65536, 5)])
 def test_pcm16_conversions_match_the_host(n, off):
     """swc_pcm16_to_f32 / swc_f32_to_pcm16 (include/swc.h; the file loop of inference.py) against the host arithmetic of

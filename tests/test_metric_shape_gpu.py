@@ -21,7 +21,7 @@ import torch
 
 from common import ROOT, golden, oracle
 from test_parity_gpu import TOL_BF16, _relerr, _report, model
-from test_stages_gpu import TOL as STAGE_TOL
+from test_stages_gpu import TOL as STAGE_TOL, _to_f32
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -90,7 +90,7 @@ def test_stage_decoder_fused_mlp_kernel(name, fusion):
         with torch.cuda.device(0), torch.inference_mode(), _Spy("mlp_block") as spy1, _Spy("layer_tail") as spy2, \
                 _Spy("layernorm") as ln:
             P = m._packed()
-            mel = m._decoder(up.reshape(B * Tt, D).clone(), lat, B, Tt, P).float().cpu().numpy()
+            mel = _to_f32(m._decoder(up.reshape(B * Tt, D).clone(), lat, B, Tt, P), P.vin)[..., :P.vin].cpu().numpy()
     finally:
         m.fused_layer_mlp_min_rows, m.layer_fusion = keep, keep_f
         if fusion != keep_f:

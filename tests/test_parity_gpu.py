@@ -15,7 +15,8 @@ DEV = "cuda"
 
 # waveform tolerances, relative to the golden waveform's peak amplitude
 TOL_FP32 = 5e-5   # fp32 MFMA path vs the reference fp32 CPU path (measured 1-3e-6 on MI355X)
-TOL_BF16 = 5e-2   # bf16 MFMA decode (fp32 accumulate + residual stream) given IDENTICAL codes (measured 1.2-2.1e-2)
+TOL_BF16 = 2.5e-2  # bf16 MFMA decode (f32 accumulate + residual stream) given IDENTICAL codes: north_star allows 5e-2; measured 0.6-1.1e-2
+#                    since the ISTFT head runs on split-f16 operands (round 4), 1.2-2.1e-2 with every decode stage on bf16
 TOL_F16S = 1e-4   # split-f16 x3 MFMA decode (preset `f16s`: f32-class operands on both sides; refit GELU / sine of the f32 path)
 
 _MODELS = {}
@@ -104,6 +105,40 @@ def test_decode_waveform(tag, name, precision, tol):
         worst = max(worst, e)
     _report(f"decode/{tag}/{name}/{precision}", rel_err=worst)
     assert worst < tol, worst
+
+
+@pytest.mark.parametrize("opts,bound", [((True, False, False, False), 1.2e-2), ((True, True, False, False), 9e-3),
+                                         ((True, True, True, False), 8e-3), ((True, True, True, True), 8e-3),
+                                         ((False, False, False, False), TOL_BF16)])
+def test_decode_small_stage_options(opts, bound):
+    """The `mixed` preset's decode with the small stages around the bf16 decoder layers / ConvNeXt blocks on split-f16 operands
+    (AudioCodec.vocos_head_split_f16 — the default —, decoder_io_split_f16, upsample_split_f16) and plain-f16 operands inside the
+    fused ConvNeXt block (convnext_f16), against the reference's own waveforms: every combination the codec offers stays inside
+    the preset's tolerance, and each step towards f32-class stages tightens the measured error (modules.py:601-631, 437-474,
+    1053-1082)."""
+    import simwhisper_codec_amd.codec as C
+    names = ("vocos_head_split_f16", "decoder_io_split_f16", "upsample_split_f16", "convnext_f16")
+    m = model("real", "mixed")
+    keep = {n: getattr(m, n) for n in names}
+    keep_rows = m.fused_mlp_min_rows
+    try:
+        for n, v in zip(names, opts):
+            setattr(m, n, v)
+        m._pk = None
+        m.fused_mlp_min_rows = 0     # (the fused block kernel, where convnext_f16 lives)
+        worst = 0.0
+        for name in ("single", "ragged", "short"):
+            g = golden("real", name)
+            nutt = len(g["spec_n"])
+            wav = m.decode([torch.from_numpy(g[f"codes_{i}"]).to(DEV) for i in range(nutt)])["syn_wav_list"]
+            worst = max([worst] + [_relerr(wav[i].float().cpu().numpy(), g[f"wav_{i}"]) for i in range(nutt)])
+        _report("decode_options/real/" + "".join("1" if v else "0" for v in opts), rel_err=worst)
+        assert worst < bound, worst
+    finally:
+        for n, v in keep.items():
+            setattr(m, n, v)
+        m.fused_mlp_min_rows = keep_rows
+        m._pk = None
 
 
 @pytest.mark.parametrize("tag", ["tiny", "real"])

@@ -9,7 +9,8 @@ Tolerances:
   fp32   every stage <= 1e-4 (measured on MI355X: mel 3.4-4.5e-5 (log10 of small powers), every other stage 0.6-2.2e-6)
   mixed  encode-side stages (split-f16 x3, f32-class) <= 1e-4 (measured 0.8-1.2e-6); decode-side stages (bf16 operands,
          f32 accumulate and residual stream) per stage, about 2x the values measured on MI355X:
-         up 4.4-5.2e-3, dec_mel 4.4-6.7e-3, y 0.9-1.4e-2, forward() 1.0-1.6e-2
+         up 4.4-5.2e-3, dec_mel 4.4-6.7e-3, y 2.9-3.1e-3 (ISTFT head on split-f16 operands since round 4; 0.9-1.4e-2 before),
+         forward() 1.0-1.6e-2 before, 0.5-0.9e-2 after
 """
 import os
 
@@ -29,7 +30,8 @@ TOL = {
     "z": (1e-4, 1e-4),         # down-sampler (snake_aa, k7 convs)
     "up": (1e-4, 1.2e-2),      # up-sampler: bf16 operands
     "dec_mel": (1e-4, 1.5e-2), # 12 decoder layers + deconvs: bf16 operands
-    "y": (1e-4, 3e-2),         # Vocos + ISTFT: bf16 operands, refit-sigmoid GELU, hardware sine
+    "y": (1e-4, 8e-3),         # Vocos + ISTFT: bf16 operands in the backbone, refit-sigmoid GELU, hardware sine; the ISTFT head on
+    #                            split-f16 operands (round 4: measured 2.9 - 3.1e-3; 1.2 - 1.4e-2 with a bf16 head)
 }
 
 _MODELS = {}
@@ -59,9 +61,10 @@ def _relerr(a, b):
 def _to_f32(t, cols):
     """operand-format tensor [..., storage cols] -> f32 [..., cols] (split-f16: (hi + lo) / 64)."""
     from simwhisper_codec_amd import ops
-    if t.dtype == torch.float16:
-        v = t.reshape(-1, cols // 32, 2, 32).float()
-        return ((v[:, :, 0] + v[:, :, 1]) / ops.F16S_ACT_SCALE).reshape(*t.shape[:-1], cols)
+    if t.dtype == torch.float16:  # (storage may be padded to a multiple of 32 logical columns: the decoder's 80-channel mel is 96 wide)
+        kc = t.shape[-1] // 2
+        v = t.reshape(-1, kc // 32, 2, 32).float()
+        return ((v[:, :, 0] + v[:, :, 1]) / ops.F16S_ACT_SCALE).reshape(*t.shape[:-1], kc)   # all logical columns, padding included
     return t.float()
 
 
@@ -154,7 +157,7 @@ def test_stage_decoder(tag, name, precision):
     with torch.cuda.device(0), torch.inference_mode():
         P = m._packed()
         mel = m._decoder(up.reshape(B * Tt, D).clone(), lat, B, Tt, P)
-        got = _to_f32(mel, P.vin).cpu().numpy()
+        got = _to_f32(mel, P.vin)[..., :P.vin].cpu().numpy()
     _check("dec_mel", tag, name, precision, got, g["st_dec_mel"].transpose(0, 2, 1))
 
 

@@ -46,10 +46,14 @@ def timed(fn, n=10):
 
 
 outs, res = {}, {v: {"encode": [], "decode": [], "step": []} for v in vals}
+PACK_TIME = ("layer_fusion", "conv1_split_f16", "convnext_f16", "vocos_head_split_f16", "decoder_io_split_f16", "upsample_split_f16")
+
+
 def setv(v):
-    setattr(m, a.attr, v)
-    if a.attr in ("layer_fusion", "conv1_split_f16"):   # read at pack time: re-pack
-        m._pk = None
+    for name in a.attr.split(","):   # several attributes at once: "vocos_head_split_f16,decoder_io_split_f16,upsample_split_f16"
+        setattr(m, name, v)
+        if name in PACK_TIME:   # read at pack time: re-pack
+            m._pk = None
 
 
 for v in vals:

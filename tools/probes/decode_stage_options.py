@@ -1,0 +1,22 @@
+"""Waveform error of the `mixed` preset's decode against the reference's own waveforms (fixtures) for every combination of the three
+split-f16 small-stage options.  usage: python tools/probes/decode_stage_options.py"""
+import itertools, os, sys
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+from common import golden
+from test_parity_gpu import _relerr, model
+
+m = model("real", "mixed")
+for head, io, up in itertools.product((False, True), repeat=3):
+    m.vocos_head_split_f16, m.decoder_io_split_f16, m.upsample_split_f16 = head, io, up
+    m._pk = None
+    errs = []
+    for name in ("single", "ragged", "short"):
+        g = golden("real", name)
+        n = len(g["spec_n"])
+        codes = [torch.from_numpy(g[f"codes_{i}"]).cuda() for i in range(n)]
+        wav = m.decode(codes)["syn_wav_list"]
+        errs.append(max(_relerr(wav[i].cpu().numpy(), g[f"wav_{i}"]) for i in range(n) if g[f"wav_{i}"].size))
+    print(f"head={head!s:5s} io={io!s:5s} up={up!s:5s}  " + "  ".join(f"{e:.2e}" for e in errs), flush=True)
