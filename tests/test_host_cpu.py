@@ -331,7 +331,8 @@ def test_build_options_still_compile(tmp_path):
     jobs = [(["-DCX_MFMA16=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], "swc_convnext.hip"),
             (["-DCX_RES_ACC=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], "swc_convnext.hip"),
             (["-DML_ABL=63", "-DML_PF=8", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], "swc_mlp.hip"),
-            (["-DATT_ABL=62"], "swc_attention16.hip"), (["-DATT_RES=1"], "swc_attention16.hip")]
+            (["-DATT_ABL=62"], "swc_attention16.hip"), (["-DATT_RES=1"], "swc_attention16.hip"),
+            (["-DPL_ABL=29", "-DPL_PF=48", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], "swc_projln.hip")]
     procs = [subprocess.Popen(common + flags + [os.path.join(csrc, src), "-o", str(tmp_path / (f"{i}_{src}.o"))],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for i, (flags, src) in enumerate(jobs)]
     for (flags, src), p in zip(jobs, procs):
