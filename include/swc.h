@@ -363,7 +363,8 @@ int swc_deconv_col2im(const float* y3, const float* bias, void* out, int64_t ldo
 /*
  * ISTFT head (modules.py:1065-1081, 861-884):
  *  spec: h [rows][ldh] (mag 0..320 | phase 321..641) -> s [rows][lds]:
- *        re = min(exp(mag),100)*cos(p) at col k, im at col 321+k, pad zero.
+ *        re = min(exp(mag),100)*cos(p) at col k, im at col 321+k, pad zero.  s_dtype F32 | BF16 | F16S (split-f16 at
+ *        SWC_F16S_ACT_SCALE, lds % 32 == 0: what swc_cast_f32_f16s would write for the same values, |S| <= 100).
  *  ola : frames [B][T][640] (windowed inverse DFT, a swc_gemm) -> wav [B][T*160]:
  *        overlap-add hop 160, crop 240, divide by the hann^2 envelope.
  */

@@ -1036,9 +1036,7 @@ class AudioCodec(nn.Module):
         hn = ops.layernorm(x, P.vfin[0], P.vfin[1], 1e-6, B=B, t_in=Tv, C_=C, out_dtype=torch.float16 if t16 else dt)
         ho = torch.empty((M, 648), device=mel.device, dtype=torch.float32)  # ld 648: 16-byte rows for vector stores
         self._mm(hn.view(M, -1), P.hw, M, 642, C, lda=C, bias=P.hb, out=ho, ldc=648)
-        sp = ops.istft_spec(ho, 648, M, P.idft_k, out_dtype=torch.float32 if t16 else dt)
-        if t16:
-            sp = ops.cast_f16s(sp, P.idft_k)
+        sp = ops.istft_spec(ho, 648, M, P.idft_k, out_dtype=torch.float16 if t16 else dt)   # (split-f16 written directly)
         fr = self._mm(sp, P.idft, M, 640, P.idft_k, lda=P.idft_k)
         return ops.istft_ola(fr, P.wsq, B=B, T=Tv)
 

@@ -708,6 +708,20 @@ __global__ void deconv_col2im4_kernel(const float* __restrict__ y3, const float*
 
 // -------------------------------------------------------------------- ISTFT
 // one thread per (row, bin): magnitude and phase are read once and feed both the real and the imaginary column
+// (split-f16 output, the ISTFT head of the 16-bit decode presets since round 4: the halves swc_cast_f32_f16s would write for the same
+// value at SWC_F16S_ACT_SCALE — |S| <= 100 by the clip below, nothing to saturate)
+template <typename OutT>
+__device__ __forceinline__ void spec_store(OutT* s, long r, long lds, int col, float v) {
+    if constexpr (__is_same(OutT, f16s_t)) {
+        unsigned short* row = reinterpret_cast<unsigned short*>(s) + r * lds * 2;
+        unsigned short hi, lo;
+        f16s_split(v * SWC_F16S_ACT_SCALE, hi, lo);
+        row[f16s_col(col)] = hi;
+        row[f16s_col(col) + 32] = lo;
+    } else {
+        store_out<OutT>(s + r * lds + col, v);
+    }
+}
 template <typename OutT>
 __global__ void istft_spec2_kernel(const float* __restrict__ h, long ldh, OutT* __restrict__ s, long lds, long rows) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -716,14 +730,14 @@ __global__ void istft_spec2_kernel(const float* __restrict__ h, long ldh, OutT* 
     const long r = i / per;
     const int k = (int)(i - r * per);
     if (k >= 321) {
-        store_out<OutT>(s + r * lds + 642 + (k - 321), 0.f);
+        spec_store<OutT>(s, r, lds, 642 + (k - 321), 0.f);
         return;
     }
     float mag = expf(h[r * ldh + k]);
     mag = fminf(mag, 100.0f);
     const float ph = h[r * ldh + 321 + k];
-    store_out<OutT>(s + r * lds + k, mag * cosf(ph));
-    store_out<OutT>(s + r * lds + 321 + k, mag * sinf(ph));
+    spec_store<OutT>(s, r, lds, k, mag * cosf(ph));
+    spec_store<OutT>(s, r, lds, 321 + k, mag * sinf(ph));
 }
 
 __global__ __launch_bounds__(256) void istft_ola_kernel(const float* __restrict__ frames, const float* __restrict__ wsq,
@@ -1051,14 +1065,17 @@ extern "C" int swc_deconv_col2im(const float* y3, const float* bias, void* out, 
 extern "C" int swc_istft_spec(const float* h, int64_t ldh, void* sp, int64_t lds, int64_t rows, int32_t s_dtype,
                               void* stream) {
     SWC_CHECK_ARG(h && sp && ldh >= 642 && lds >= 642, "swc_istft_spec: bad args");
+    SWC_CHECK_ARG(s_dtype != SWC_F16S || lds % 32 == 0, "swc_istft_spec: split-f16 rows need lds %% 32 == 0 (lds=%ld)", (long)lds);
     if (rows <= 0) return SWC_OK;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(nblk(rows * (321 + (lds - 642)), 256));
-    OUT_DISPATCH(s_dtype,
-                 hipLaunchKernelGGL(istft_spec2_kernel<float>, grid, dim3(256), 0, s, h, (long)ldh, (float*)sp,
-                                    (long)lds, (long)rows),
-                 hipLaunchKernelGGL(istft_spec2_kernel<bf16_t>, grid, dim3(256), 0, s, h, (long)ldh, (bf16_t*)sp,
-                                    (long)lds, (long)rows));
+    OUT_DISPATCH3(s_dtype,
+                  hipLaunchKernelGGL(istft_spec2_kernel<float>, grid, dim3(256), 0, s, h, (long)ldh, (float*)sp,
+                                     (long)lds, (long)rows),
+                  hipLaunchKernelGGL(istft_spec2_kernel<bf16_t>, grid, dim3(256), 0, s, h, (long)ldh, (bf16_t*)sp,
+                                     (long)lds, (long)rows),
+                  hipLaunchKernelGGL(istft_spec2_kernel<f16s_t>, grid, dim3(256), 0, s, h, (long)ldh, (f16s_t*)sp,
+                                     (long)lds, (long)rows));
     SWC_CHECK_LAUNCH("swc_istft_spec");
     return SWC_OK;
 }

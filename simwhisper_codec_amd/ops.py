@@ -222,7 +222,7 @@ def deconv_col2im(y3, bias, *, B, T, C_, s, t_out, ldo=None, out_dtype=torch.flo
 
 def istft_spec(h, ldh, rows, lds, out_dtype=torch.float32):
     lib = _lib.load()
-    s = torch.empty((rows, lds), device=h.device, dtype=out_dtype)
+    s = torch.empty((rows, _w(out_dtype, lds)), device=h.device, dtype=out_dtype)   # (float16 = split-f16: 2 halves per column)
     _lib.check(lib.swc_istft_spec(_ptr(h), ldh, _ptr(s), lds, rows, _DT[out_dtype], _stream()), "swc_istft_spec")
     return s
 

@@ -363,6 +363,12 @@ def test_istft():
     assert (sp[:, :321].double() - mag * torch.cos(ph)).abs().max().item() < 2e-4
     assert (sp[:, 321:642].double() - mag * torch.sin(ph)).abs().max().item() < 2e-4
     assert (sp[:, 642:] == 0).all()
+    # split-f16 output (the ISTFT head of the 16-bit decode presets): the halves swc_cast_f32_f16s writes for the same values
+    sp16 = ops.istft_spec(h.to(DEV), 656, B * T, 672, out_dtype=torch.float16)
+    assert sp16.shape == (B * T, 2 * 672) and torch.equal(sp16, ops.cast_f16s(sp.to(DEV), 672))
+    from simwhisper_codec_amd._lib import SwcError
+    with pytest.raises(SwcError):
+        ops.istft_spec(h.to(DEV), 656, B * T, 648, out_dtype=torch.float16)   # 648 is not a multiple of the 32-column split block
     # overlap-add against the fold-based statement (modules.py:861-884)
     win = torch.hann_window(640, dtype=torch.float64)
     frames = torch.randn(B, T, 640, generator=g).double()  # already windowed inverse DFT rows
