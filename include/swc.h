@@ -255,6 +255,10 @@ int swc_mlp_block(const float* x, float* x_out, const float* ln_w, const float* 
  * per-tensor power-of-two scale sw, the kernel writes LayerNorm(x') to LDS as e4m3 at SWC_FP8_ACT_SCALE (clipping is counted:
  * swc_set_saturation_counter) and multiplies fc1's accumulators by fc1_alpha = 1 / (SWC_FP8_ACT_SCALE * sw); everything else stays
  * bf16.  fc1_dtype = SWC_BF16: fc1_alpha is ignored.  The stream must have been packed for the same fc1_dtype.
+ * operand_dtype = SWC_BF16 | SWC_F16 (with fc1_dtype SWC_BF16 = "16-bit"): the type of the kernel's INTERNAL MFMA operands.  SWC_F16:
+ * the attention tile is converted bf16 -> f16 in LDS (exact), LayerNorm(x') and GELU(h) are written as f16 and the stream holds the
+ * three weight matrices rounded to f16 (swc_layer_tail_pack re-orders 16-bit elements whatever their format): 11 significand bits
+ * instead of 8 at the same MFMA rate; conversions saturate at +-65504.  attn in and y_next out stay bf16, x / x_out f32.
  */
 int64_t swc_layer_tail_stream_bytes(int32_t D, int32_t F, int32_t fc1_dtype);
 int swc_layer_tail_pack(const void* wo_bf16, const void* w1, const void* w2_bf16, void* w_stream, int32_t D, int32_t F,
@@ -262,7 +266,7 @@ int swc_layer_tail_pack(const void* wo_bf16, const void* w1, const void* w2_bf16
 int swc_layer_tail(const void* attn, const float* x, float* x_out, const void* w_stream, const float* bo, const float* ln_w,
                    const float* ln_b, float eps, const float* b1, const float* b2, const float* next_ln_w,
                    const float* next_ln_b, void* y_next, int32_t M, int32_t D, int32_t F, int32_t fc1_dtype, float fc1_alpha,
-                   void* stream);
+                   int32_t operand_dtype, void* stream);
 
 /*
  * A split-f16 projection onto the residual stream with the LayerNorm behind it in one kernel — the `mixed` encoder's

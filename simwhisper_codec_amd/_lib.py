@@ -78,7 +78,7 @@ SIGNATURES = {
     "swc_mlp_pack": [_P, _P, _P, _I, _I, _P],
     "swc_mlp_block": [_P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "swc_layer_tail_pack": [_P, _P, _P, _P, _I, _I, _I, _P],
-    "swc_layer_tail": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P],
+    "swc_layer_tail": [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "swc_proj_ln_pack": [_P, _P, _I, _I, _P],
     "swc_proj_ln": [_P, _L, _P, _P, _F, _P, _P, _P, _P, _F, _P, _I, _I, _I, _P],
 }

@@ -95,7 +95,7 @@ def _register(root, name, tensor):
 
 
 class _Layer:
-    __slots__ = ("ln1", "wqkv", "bqkv", "wo", "bo", "ln2", "w1", "b1", "w2", "b2", "ws", "wts")  # ws / wts: operand streams of swc_mlp_block / swc_layer_tail (bf16)
+    __slots__ = ("ln1", "wqkv", "bqkv", "wo", "bo", "ln2", "w1", "b1", "w2", "b2", "ws", "wts", "t16")  # ws / wts: operand streams of swc_mlp_block / swc_layer_tail; t16: wts holds plain-f16 weights
 
 
 class _Packed:
@@ -585,7 +585,17 @@ class AudioCodec(nn.Module):
                 f8fc1 = fc1_dt == ops.FP8_T   # (preset fp8_fc1: swc_layer_tail runs fc1 on the fp8 MFMA; swc_mlp_block is bf16 only)
                 # (one stream per layer and form, ~10 MB each: only the form `layer_fusion` selects at pack time is built)
                 L.ws = ops.mlp_pack(L.w1.w, L.w2.w) if ok and not f8fc1 and self.layer_fusion == 1 else None
-                L.wts = ops.layer_tail_pack(L.wo.w, L.w1.w, L.w2.w) if ok and self.layer_fusion >= 2 else None
+                L.wts, L.t16 = None, False
+                if ok and self.layer_fusion >= 2:
+                    f32w = [sd[p + k] for k in ("self_attn.out_proj.weight", "fc1.weight", "fc2.weight")]
+                    # plain f16 inside the kernel (11 significand bits for weights, LayerNorm output, GELU output) when the weights
+                    # are representable; the kernel saturates its conversions at +-65504
+                    L.t16 = bool(self.layer_tail_f16 and not f8fc1 and
+                                 all(bool(torch.isfinite(t).all()) and float(t.abs().max()) < 8192.0 for t in f32w))
+                    if L.t16:
+                        L.wts = ops.layer_tail_pack(*[V(t).to(torch.float16) for t in f32w])
+                    else:
+                        L.wts = ops.layer_tail_pack(L.wo.w, L.w1.w, L.w2.w)
                 out.append(L)
             return out
 
@@ -762,7 +772,8 @@ class AudioCodec(nn.Module):
             if fused and self.layer_fusion >= 2 and getattr(L, "wts", None) is not None:
                 # out-proj + residual + LayerNorm + MLP + residual + next LayerNorm: one kernel
                 _, x = ops.layer_tail(a, h, L.wts, L.bo, L.ln2[0], L.ln2[1], 1e-5, L.b1, L.b2, M=M, D=D, F=F_, next_ln=nxt,
-                                      fc1_dtype=L.w1.w.dtype, fc1_alpha=L.w1.alpha)
+                                      fc1_dtype=L.w1.w.dtype, fc1_alpha=L.w1.alpha,
+                                      operands=torch.float16 if getattr(L, "t16", False) else torch.bfloat16)
                 continue
             self._mm(a, L.wo, M, D, D, lda=D, bias=L.bo, residual=h, out=h)
             if fused and self.layer_fusion == 1:
@@ -815,8 +826,11 @@ class AudioCodec(nn.Module):
     # 16-bit decode presets (read at pack time): small stages around the decoder layers and the ConvNeXt blocks on split-f16
     # operands — f32-class arithmetic where the waveform sees rounding undamped (measured at 32 x 10 s,
     # waveform error against the reference / decode time: profiles/r04_decode_error_budget.txt):
-    #   none 1.5 - 1.8e-2 | head 8.5e-3, +0.10 ms | head + io 6.5e-3, +0.35 ms | head + io + up 5.8e-3, +0.6 ms (the 12 bf16 decoder
-    #   layers alone: 5.3 - 6.0e-3).  The head is on: half the error for 0.5 % of the step; the other two are there to be switched on
+    #   none 1.5 - 1.8e-2 | head 8.5e-3, +0.05 ms | head + io 6.5e-3, +0.30 ms | head + io + up 5.8e-3, +0.55 ms (the 12 bf16 decoder
+    #   layers alone: 5.3 - 6.0e-3) | with layer_tail_f16 (+0.07 ms): 7.0e-3 / 5.2e-3 / 3.6e-3.
+    # The head and the f16 layer tail are on: 2.5 x less error for 0.6 % of the step; the other two are there to be switched on
+    layer_tail_f16 = True          # swc_layer_tail's internal operands (attention tile, LayerNorm output, GELU output, weights) in plain f16
+    #                                instead of bf16 (8 x smaller operand rounding at the same MFMA rate; conversions saturate at +-65504)
     vocos_head_split_f16 = True    # final LayerNorm -> Linear 512 -> 642 -> exp / cos / sin -> inverse DFT
     decoder_io_split_f16 = False   # decoder: final LayerNorm -> deconv1 -> deconv2 -> mel; Vocos: embed conv
     upsample_split_f16 = False     # FrameStackUpConv: from_latent, 3 residual units (snake + k7 / k1 convs), to_stacked

@@ -19,7 +19,7 @@ extern "C" int swc_set_saturation_counter(uint32_t* dev_counters) {
     return SWC_OK;
 }
 
-extern "C" int swc_version(void) { return 205; }  // 2.05: swc_convnext_block takes operand_dtype (SWC_BF16 | SWC_F16); 2.04: swc_proj_ln (+ _pack, _stream_bytes); 2.03: swc_convnext_pack folds gamma into the stream; 2.02: swc_mlp_block / swc_layer_tail + their packed operand streams (2.01: swc_convnext_block takes per-utterance frame limits; 2.00: saturation counter, fused ConvNeXt, packed layouts)
+extern "C" int swc_version(void) { return 206; }  // 2.06: swc_layer_tail takes operand_dtype; 2.05: swc_convnext_block takes operand_dtype (SWC_BF16 | SWC_F16); 2.04: swc_proj_ln (+ _pack, _stream_bytes); 2.03: swc_convnext_pack folds gamma into the stream; 2.02: swc_mlp_block / swc_layer_tail + their packed operand streams (2.01: swc_convnext_block takes per-utterance frame limits; 2.00: saturation counter, fused ConvNeXt, packed layouts)
 
 extern "C" const char* swc_last_error(void) { return g_err; }
 

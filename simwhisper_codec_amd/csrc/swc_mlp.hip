@@ -77,15 +77,25 @@ __device__ __forceinline__ unsigned ml_pack_bf16x2(float lo, float hi) {
 
 // GEMM1's MFMAs of one k-step in VGPR form: 2 hidden blocks x 2 token blocks (see mfma32x4_vgpr in swc_convnext.hip for why
 // these are asm: left to hipcc both accumulator sets get AGPR-form MFMAs and are shuffled between the register halves)
+template <bool F16 = false>
 __device__ __forceinline__ void ml_mfma2x2_vgpr(const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1,
                                                 f32x16& c00, f32x16& c01, f32x16& c10, f32x16& c11) {
-    asm("s_nop 1\n\t"
-        "v_mfma_f32_32x32x16_bf16 %0, %4, %6, %0\n\t"
-        "v_mfma_f32_32x32x16_bf16 %1, %4, %7, %1\n\t"
-        "v_mfma_f32_32x32x16_bf16 %2, %5, %6, %2\n\t"
-        "v_mfma_f32_32x32x16_bf16 %3, %5, %7, %3"
-        : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11)
-        : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+    if constexpr (F16)
+        asm("s_nop 1\n\t"
+            "v_mfma_f32_32x32x16_f16 %0, %4, %6, %0\n\t"
+            "v_mfma_f32_32x32x16_f16 %1, %4, %7, %1\n\t"
+            "v_mfma_f32_32x32x16_f16 %2, %5, %6, %2\n\t"
+            "v_mfma_f32_32x32x16_f16 %3, %5, %7, %3"
+            : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11)
+            : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+    else
+        asm("s_nop 1\n\t"
+            "v_mfma_f32_32x32x16_bf16 %0, %4, %6, %0\n\t"
+            "v_mfma_f32_32x32x16_bf16 %1, %4, %7, %1\n\t"
+            "v_mfma_f32_32x32x16_bf16 %2, %5, %6, %2\n\t"
+            "v_mfma_f32_32x32x16_bf16 %3, %5, %7, %3"
+            : "+v"(c00), "+v"(c01), "+v"(c10), "+v"(c11)
+            : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
 }
 
 // fp8 fc1: one W1 fragment (16 hidden x 128 k, e4m3) against the four token tiles, accumulators in VGPRs (given the builtin, hipcc
@@ -102,9 +112,30 @@ __device__ __forceinline__ void ml_mfma8_1x4_vgpr(const i32x8& a, const i32x8& b
         : "v"(a), "v"(b0), "v"(b1), "v"(b2), "v"(b3), "v"(sc));
 }
 
+template <bool F16 = false>
 __device__ __forceinline__ f32x16 ml_mfma32(const u32x4& a, const u32x4& b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b),
-                                                   c, 0, 0, 0);
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&a), *reinterpret_cast<const f16x8*>(&b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b),
+                                                       c, 0, 0, 0);
+}
+
+// F16 (operand_dtype SWC_F16, with OPROJ): every MFMA operand INSIDE the kernel — the attention tile (converted in LDS: bf16 -> f16 is
+// exact), LayerNorm(x'), GELU(h) and the three weight matrices of the stream — is IEEE half precision instead of bf16: 11
+// significand bits instead of 8 at the same MFMA rate.  f16 has a finite range where bf16 has f32's: conversions saturate at
+// +-65504 (one v_med3 per value; LayerNorm outputs and weights cannot get there, a hidden activation could in principle).
+template <bool F16>
+__device__ __forceinline__ unsigned ml_pack_x2(float lo, float hi) {
+    if constexpr (F16) {
+        lo = __builtin_amdgcn_fmed3f(lo, -65504.0f, 65504.0f);
+        hi = __builtin_amdgcn_fmed3f(hi, -65504.0f, 65504.0f);
+        unsigned r;
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    } else {
+        return ml_pack_bf16x2(lo, hi);
+    }
 }
 
 struct MlNorm {
@@ -139,7 +170,7 @@ static_assert(ML_P0 % ML_PF == 0, "the ring index of a fragment must not depend 
 // stream as e4m3 at its per-tensor power-of-two scale (half the bytes per slice), the 16 x 16 accumulator tiles get
 // alpha1 = 1 / (act scale x weight scale), bias and GELU and are written to the H buffer in the 32 x 32 x 16 B-fragment layout
 // (8 bytes per lane: 4 consecutive hidden values of one token), where fc2 reads them as before — in bf16, natural k order.
-template <bool OPROJ, bool F8 = false>
+template <bool OPROJ, bool F8 = false, bool F16 = false>
 __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float* xo, MlNorm ln, float eps,
                                                            const u32x4* __restrict__ wstream, const float* __restrict__ b1,
                                                            const float* __restrict__ b2, MlNorm nln,
@@ -147,6 +178,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
                                                            const bf16_t* __restrict__ att, const float* __restrict__ bo,
                                                            float alpha1, unsigned* sat) {
     static_assert(!F8 || OPROJ, "the fp8 fc1 exists for the layer-tail form");
+    static_assert(!F16 || (OPROJ && !F8), "half-precision operands exist for the bf16 layer-tail form");
     constexpr int G1F = F8 ? ML_FPP / 2 : ML_FPP;  // 1 KiB stream entries of one GEMM1 phase (e4m3: half the bytes)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -283,6 +315,20 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
         for (int i = 0; i < ML_PF; ++i) ring[i] = wfrag(i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if constexpr (F16) {
+            // the attention tile arrived as bf16: to f16 in place (exact: 8 significand bits into 11; saturating).  A lane rewrites the
+            // 16 bytes it read: 24 fragments per wave
+#pragma unroll 4
+            for (int i = 0; i < 2 * ML_KS1 / 4; ++i) {
+                u32x4* fp = reinterpret_cast<u32x4*>(smem + (w * (2 * ML_KS1 / 4) + i) * ML_YP) + lane;
+                const u32x4 v = *fp;
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = ml_pack_x2<true>(__uint_as_float(v[e] << 16), __uint_as_float(v[e] & 0xffff0000u));
+                *fp = o;
+            }
+            __syncthreads();
+        }
         // (3) x' = x + att Wo^T + bo: 48 k-steps of 12 MFMAs over the attention image
         {
             u32x4 aA[2], aB[2];
@@ -292,7 +338,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
 #pragma unroll
                 for (int n = 0; n < ML_NB; ++n) {
 #pragma unroll
-                    for (int b = 0; b < 2; ++b) acc2[n][b] = ml_mfma32(ring[(s_ * ML_NB + n) % ML_PF], cur[b], acc2[n][b]);
+                    for (int b = 0; b < 2; ++b) acc2[n][b] = ml_mfma32<F16>(ring[(s_ * ML_NB + n) % ML_PF], cur[b], acc2[n][b]);
                     ring[(s_ * ML_NB + n) % ML_PF] = wfrag(s_ * ML_NB + n + ML_PF);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -378,8 +424,13 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
                                           o[4 * hq + 3] * SWC_FP8_ACT_SCALE, amax8);
                         }
                     } else {
-                        *reinterpret_cast<u32x4*>(smem + (2 * (12 * w + 2 * n + t) + fb) * ML_YP + lane * 16) =
-                            (u32x4){bf16_pack2(o[0], o[1]), bf16_pack2(o[2], o[3]), bf16_pack2(o[4], o[5]), bf16_pack2(o[6], o[7])};
+                        if constexpr (F16)
+                            *reinterpret_cast<u32x4*>(smem + (2 * (12 * w + 2 * n + t) + fb) * ML_YP + lane * 16) =
+                                (u32x4){ml_pack_x2<true>(o[0], o[1]), ml_pack_x2<true>(o[2], o[3]), ml_pack_x2<true>(o[4], o[5]),
+                                        ml_pack_x2<true>(o[6], o[7])};
+                        else
+                            *reinterpret_cast<u32x4*>(smem + (2 * (12 * w + 2 * n + t) + fb) * ML_YP + lane * 16) =
+                                (u32x4){bf16_pack2(o[0], o[1]), bf16_pack2(o[2], o[3]), bf16_pack2(o[4], o[5]), bf16_pack2(o[6], o[7])};
                     }
                 }
         }
@@ -421,7 +472,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
         for (int s = 0; s < ML_KS1; s += 2) {
             {
                 y_frags(s + 1, yB);
-                ml_mfma2x2_vgpr(ring[(2 * s) % ML_PF], ring[(2 * s + 1) % ML_PF], yA[0], yA[1], acc1[0][0], acc1[0][1], acc1[1][0],
+                ml_mfma2x2_vgpr<F16>(ring[(2 * s) % ML_PF], ring[(2 * s + 1) % ML_PF], yA[0], yA[1], acc1[0][0], acc1[0][1], acc1[1][0],
                                 acc1[1][1]);
                 ring[(2 * s) % ML_PF] = wfrag(2 * s + ML_PF);
                 ring[(2 * s + 1) % ML_PF] = wfrag(2 * s + 1 + ML_PF);
@@ -429,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
             }
             {
                 y_frags((s + 2) % ML_KS1, yA);  // the last step re-reads step 0 (harmless)
-                ml_mfma2x2_vgpr(ring[(2 * s + 2) % ML_PF], ring[(2 * s + 3) % ML_PF], yB[0], yB[1], acc1[0][0], acc1[0][1],
+                ml_mfma2x2_vgpr<F16>(ring[(2 * s + 2) % ML_PF], ring[(2 * s + 3) % ML_PF], yB[0], yB[1], acc1[0][0], acc1[0][1],
                                 acc1[1][0], acc1[1][1]);
                 ring[(2 * s + 2) % ML_PF] = wfrag(2 * s + 2 + ML_PF);
                 ring[(2 * s + 3) % ML_PF] = wfrag(2 * s + 3 + ML_PF);
@@ -447,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (ML_ABL & 2) ? acc1[hb][b][8 * t + 4 * h + e] : gelu_fast(acc1[hb][b][8 * t + 4 * h + e]);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) acc1[hb][b][4 * t + 2 * h + i] = __uint_as_float(ml_pack_bf16x2(v[2 * i], v[2 * i + 1]));
+        for (int i = 0; i < 2; ++i) acc1[hb][b][4 * t + 2 * h + i] = __uint_as_float(ml_pack_x2<F16>(v[2 * i], v[2 * i + 1]));
     };
     auto store_h = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -543,7 +594,7 @@ __global__ __launch_bounds__(256, 1) void mlp_block_kernel(const float* x, float
 #pragma unroll
             for (int n = 0; n < ML_NB; ++n) {
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc2[n][b] = ml_mfma32(ring[(q * ML_NB + n) % ML_PF], cur[b], acc2[n][b]);
+                for (int b = 0; b < 2; ++b) acc2[n][b] = ml_mfma32<F16>(ring[(q * ML_NB + n) % ML_PF], cur[b], acc2[n][b]);
                 ring[(q * ML_NB + n) % ML_PF] = wfrag(q * ML_NB + n + ML_PF);
             }
             if constexpr (decltype(with_gelu)::value) {
@@ -819,7 +870,9 @@ extern "C" int swc_layer_tail_pack(const void* wo, const void* w1, const void* w
 extern "C" int swc_layer_tail(const void* attn, const float* x, float* x_out, const void* w_stream, const float* bo,
                               const float* ln_w, const float* ln_b, float eps, const float* b1, const float* b2,
                               const float* next_ln_w, const float* next_ln_b, void* y_next, int32_t M, int32_t D, int32_t F,
-                              int32_t fc1_dtype, float fc1_alpha, void* stream) {
+                              int32_t fc1_dtype, float fc1_alpha, int32_t operand_dtype, void* stream) {
+    SWC_CHECK_ARG(operand_dtype == SWC_BF16 || (operand_dtype == SWC_F16 && fc1_dtype == SWC_BF16),
+                  "swc_layer_tail: operand_dtype must be BF16, or F16 with a 16-bit fc1");
     SWC_CHECK_ARG(attn && x && x_out && bo && ln_w && ln_b && w_stream && b1 && b2, "swc_layer_tail: null pointer");
     SWC_CHECK_ARG(!y_next || (next_ln_w && next_ln_b), "swc_layer_tail: y_next needs next_ln_w / next_ln_b");
     SWC_CHECK_ARG(D == ML_D && F > 0 && F % ML_SL == 0, "swc_layer_tail: needs D = %d and F a multiple of %d (D=%d F=%d)", ML_D,
@@ -837,6 +890,11 @@ extern "C" int swc_layer_tail(const void* attn, const float* x, float* x_out, co
         hipLaunchKernelGGL((mlp_block_kernel<true, true>), dim3(grid), dim3(256), ML_LDS, (hipStream_t)stream, x, x_out,
                            MlNorm{ln_w, ln_b}, eps, (const u32x4*)w_stream, b1, b2, MlNorm{next_ln_w, next_ln_b}, (bf16_t*)y_next, M,
                            F / ML_SL, (const bf16_t*)attn, bo, fc1_alpha, swc_sat_counter());
+    } else if (operand_dtype == SWC_F16) {
+        SWC_ENABLE_LDS((mlp_block_kernel<true, false, true>), ML_LDS, "swc_layer_tail");
+        hipLaunchKernelGGL((mlp_block_kernel<true, false, true>), dim3(grid), dim3(256), ML_LDS, (hipStream_t)stream, x, x_out,
+                           MlNorm{ln_w, ln_b}, eps, (const u32x4*)w_stream, b1, b2, MlNorm{next_ln_w, next_ln_b}, (bf16_t*)y_next, M,
+                           F / ML_SL, (const bf16_t*)attn, bo, 1.0f, (unsigned*)nullptr);
     } else {
         SWC_ENABLE_LDS((mlp_block_kernel<true, false>), ML_LDS, "swc_layer_tail");
         hipLaunchKernelGGL((mlp_block_kernel<true, false>), dim3(grid), dim3(256), ML_LDS, (hipStream_t)stream, x, x_out,

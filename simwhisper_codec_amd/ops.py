@@ -445,28 +445,32 @@ def layer_tail_pack(wo, w1, w2):
     """out_proj.weight [D, D] (bf16), fc1.weight [F, D] (bf16, or e4m3 at a per-tensor scale: preset fp8_fc1), fc2.weight [D, F]
     (bf16), all on the device -> the operand stream of swc_layer_tail for that fc1 operand type."""
     lib = _lib.load()
-    _chk(wo, "layer_tail_pack wo", torch.bfloat16); _chk(w2, "layer_tail_pack w2", torch.bfloat16)
+    _chk(wo, "layer_tail_pack wo"); _chk(w2, "layer_tail_pack w2", wo.dtype)
     _chk(w1, "layer_tail_pack w1")
-    if w1.dtype not in (torch.bfloat16, FP8_T):
-        raise _lib.SwcError(f"layer_tail_pack: fc1 weights must be bf16 or e4m3, got {w1.dtype}")
+    if wo.dtype not in (torch.bfloat16, torch.float16):
+        raise _lib.SwcError(f"layer_tail_pack: weights must be bf16 (or PLAIN float16 for layer_tail(operands=torch.float16)), got {wo.dtype}")
+    if w1.dtype not in (wo.dtype, FP8_T) or (w1.dtype == FP8_T and wo.dtype != torch.bfloat16):
+        raise _lib.SwcError(f"layer_tail_pack: fc1 weights must be {wo.dtype} (or e4m3 beside bf16), got {w1.dtype}")
     F_, D = w1.shape
     if tuple(w2.shape) != (D, F_) or tuple(wo.shape) != (D, D):
         raise _lib.SwcError(f"layer_tail_pack: shapes {tuple(wo.shape)} {tuple(w1.shape)} {tuple(w2.shape)}")
-    n = lib.swc_layer_tail_stream_bytes(D, F_, _DT[w1.dtype])
+    f1 = FP8 if w1.dtype == FP8_T else BF16   # (BF16 = "16-bit elements": the pack step re-orders them whatever their format)
+    n = lib.swc_layer_tail_stream_bytes(D, F_, f1)
     if n <= 0:
         raise _lib.SwcError(f"layer_tail_pack: unsupported geometry D={D} F={F_}")
     out = torch.empty(n, dtype=torch.uint8, device=w1.device)
     _lib.check(lib.swc_layer_tail_pack(_ptr(wo.contiguous()), _ptr(w1.contiguous()), _ptr(w2.contiguous()), _ptr(out), D, F_,
-                                       _DT[w1.dtype], _stream()), "swc_layer_tail_pack")
+                                       f1, _stream()), "swc_layer_tail_pack")
     return out
 
 
 def layer_tail(attn, x, w_stream, bo, ln_w, ln_b, eps, b1, b2, *, M, D, F, x_out=None, next_ln=None, y_next=None,
-               fc1_dtype=torch.bfloat16, fc1_alpha=1.0):
+               fc1_dtype=torch.bfloat16, fc1_alpha=1.0, operands=torch.bfloat16):
     """Everything of a transformer layer behind the attention in one kernel (swc_layer_tail): attn [M, D] bf16 (attention
     output), x [M, D] f32 residual stream -> x_out (default: in place) and, with next_ln = (weight, bias), the bf16
     LayerNorm output the next layer's q/k/v projection reads (second return value).  fc1_dtype = FP8_T: the stream was packed
-    from e4m3 fc1 weights (scale sw) and fc1_alpha = 1 / (FP8_ACT_SCALE * sw)."""
+    from e4m3 fc1 weights (scale sw) and fc1_alpha = 1 / (FP8_ACT_SCALE * sw).  operands = torch.float16: PLAIN half precision
+    inside the kernel (the stream packed from float16 weights); attn and y_next stay bf16."""
     lib = _lib.load()
     _chk(attn, "layer_tail attn", torch.bfloat16); _chk(x, "layer_tail x", torch.float32)
     x_out = x if x_out is None else _chk(x_out, "layer_tail x_out", torch.float32)
@@ -484,7 +488,8 @@ def layer_tail(attn, x, w_stream, bo, ln_w, ln_b, eps, b1, b2, *, M, D, F, x_out
     if prof is not None:
         prof.begin("mlp_bf16" if fc1_dtype == torch.bfloat16 else "mlp_fp8fc1", 4.0 * M * D * F + 2.0 * M * D * D)
     _lib.check(lib.swc_layer_tail(_ptr(attn), _ptr(x), _ptr(x_out), _ptr(w_stream), _ptr(bo), _ptr(ln_w), _ptr(ln_b), eps, _ptr(b1),
-                                  _ptr(b2), _ptr(nw), _ptr(nb), _ptr(y_next), M, D, F, _DT[fc1_dtype], float(fc1_alpha), _stream()),
+                                  _ptr(b2), _ptr(nw), _ptr(nb), _ptr(y_next), M, D, F, _DT[fc1_dtype], float(fc1_alpha),
+                                  SWC_F16 if operands == torch.float16 else _DT[operands], _stream()),
                "swc_layer_tail")
     if prof is not None:
         prof.end()

@@ -999,6 +999,49 @@ def test_layer_tail_fused(M, F_, with_next):
 
 
 
+@pytest.mark.parametrize("M,F_", [(64, 256), (300, 512), (16000, 3072)])
+def test_layer_tail_f16_operands(M, F_):
+    """swc_layer_tail with operand_dtype SWC_F16 (plain half precision for the attention tile, LayerNorm output, GELU output and the
+    three weight matrices inside the kernel; what the 16-bit decode presets run): against an f64 evaluation on the UNROUNDED f32
+    weights (modules.py:219-232) its error is several times below the bf16 form's on the same inputs; a hidden activation beyond
+    the f16 range saturates instead of becoming inf."""
+    ops = _ops()
+    D = 768
+    g = torch.Generator().manual_seed(M * 11 + F_)
+    x0 = torch.randn(M, D, generator=g) * 1.5 + 0.1
+    att = (torch.randn(M, D, generator=g) * 0.7).to(torch.bfloat16)
+    wo = torch.randn(D, D, generator=g) * D ** -0.5
+    bo = torch.randn(D, generator=g) * 0.2
+    lw, lb = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    nw, nb = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    w1, w2 = torch.randn(F_, D, generator=g) * D ** -0.5, torch.randn(D, F_, generator=g) * F_ ** -0.5
+    b1, b2 = torch.randn(F_, generator=g) * 0.3, torch.randn(D, generator=g) * 0.3
+    d = lambda t: t.to(DEV)
+    xp = x0.double() + att.double() @ wo.double().T + bo.double()
+    h = F.gelu(F.layer_norm(xp, (D,), lw.double(), lb.double(), 1e-5) @ w1.double().T + b1.double())
+    ref = xp + h @ w2.double().T + b2.double()
+    scale = float((ref - x0.double()).abs().max())
+    rms = {}
+    for dt in (torch.float16, torch.bfloat16):
+        wts = ops.layer_tail_pack(d(wo).to(dt), d(w1).to(dt), d(w2).to(dt))
+        x = d(x0).clone()
+        xo, yn = ops.layer_tail(d(att), x, wts, d(bo), d(lw), d(lb), 1e-5, d(b1), d(b2), M=M, D=D, F=F_, next_ln=(d(nw), d(nb)),
+                                operands=dt)
+        assert torch.isfinite(xo).all() and yn.dtype == torch.bfloat16
+        rms[dt] = float((xo.cpu().double() - ref).pow(2).mean().sqrt()) / scale
+        want = ops.layernorm(xo, d(nw), d(nb), 1e-5, B=1, t_in=M, C_=D, out_dtype=torch.bfloat16).view(M, D)
+        assert torch.equal(yn, want)
+    assert rms[torch.float16] < 0.35 * rms[torch.bfloat16], rms   # (the GELU refit, |error| <= 2.7e-4, is common to both)
+    # saturation: fc1 bias 1e5 -> hidden activations beyond 65504 are clamped, the output stays finite
+    x = d(x0).clone()
+    xo, _ = ops.layer_tail(d(att), x, wts if False else ops.layer_tail_pack(d(wo).half(), d(w1).half(), d(w2).half()), d(bo), d(lw), d(lb),
+                           1e-5, torch.full((F_,), 1e5, device=DEV), d(b2), M=M, D=D, F=F_, operands=torch.float16)
+    assert torch.isfinite(xo).all()
+    from simwhisper_codec_amd._lib import SwcError
+    with pytest.raises(SwcError):
+        ops.layer_tail(d(att), x, wts, d(bo), d(lw), d(lb), 1e-5, d(b1), d(b2), M=M, D=D, F=F_, operands=torch.float32)
+
+
 @pytest.mark.parametrize("M,K,with_ln", [(64, 768, True), (300, 3072, True), (77, 768, False), (1000, 256, True),
                                          (16000, 3072, True), (16000, 768, True)])
 def test_proj_ln_fused(M, K, with_ln):

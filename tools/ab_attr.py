@@ -46,7 +46,7 @@ def timed(fn, n=10):
 
 
 outs, res = {}, {v: {"encode": [], "decode": [], "step": []} for v in vals}
-PACK_TIME = ("layer_fusion", "conv1_split_f16", "convnext_f16", "vocos_head_split_f16", "decoder_io_split_f16", "upsample_split_f16")
+PACK_TIME = ("layer_fusion", "conv1_split_f16", "convnext_f16", "layer_tail_f16", "vocos_head_split_f16", "decoder_io_split_f16", "upsample_split_f16")
 
 
 def setv(v):
