@@ -100,7 +100,7 @@ def pmc_traffic(kind):
         return None, None
 
 
-KERNEL_NAMES = {"convnext_bf16": "swc_convnext_block (bf16)", "mlp_bf16": "swc_mlp_block (bf16)"}
+KERNEL_NAMES = {"convnext_bf16": "swc_convnext_block (bf16)", "mlp_bf16": "swc_layer_tail / swc_mlp_block (16-bit operands: f16 inside the kernel, bf16 at its boundary)"}
 
 
 def roofline_of(summ, step_ms, n_sampled, brief=False):
