@@ -5,6 +5,8 @@
 set -e
 cd "$(dirname "$0")/../simwhisper_codec_amd"
 tag=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -DSWC_TUNING "$@" -I ../include -I csrc -c csrc/swc_gemm.hip -o /tmp/gemm_$tag.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libswc_$tag.so build/swc_api.o /tmp/gemm_$tag.o build/swc_attention.o build/swc_attention16.o build/swc_pointwise.o build/swc_mlp.o build/swc_convnext64.o build/swc_convnext.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -mllvm -amdgpu-sched-strategy=max-ilp -DSWC_TUNING "$@" -I ../include -I csrc -c csrc/swc_gemm.hip -o /tmp/gemm_$tag.o
+objs=""
+for o in build/*.o; do [ "$o" = "build/swc_gemm.o" ] || objs="$objs $o"; done   # every other object of the product build
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libswc_$tag.so $objs /tmp/gemm_$tag.o
 echo built libswc_$tag.so
