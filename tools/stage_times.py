@@ -12,7 +12,7 @@ from bench import bench_inputs
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 gp = yaml.safe_load(open(os.path.join(ROOT, "config", "SimWhisperCodec.yaml")))["generator_params"]
-m = AudioCodec(gp, precision="mixed")
+m = AudioCodec(gp, precision=sys.argv[3] if len(sys.argv) > 3 else "mixed")
 m.load_state_dict(synth.synth_state_dict(gp), strict=True)
 m = m.to("cuda:0").eval()
 wavs = [w.cuda() for w in bench_inputs(B, int(secs * 16000))]
